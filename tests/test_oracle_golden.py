@@ -1,0 +1,110 @@
+"""Pin the oracle (oracle/umpr_ref.py) against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import umpr_ref as R
+from umpr_amd.synthetic import make_batch, make_param_state
+from conftest import load_golden
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("tag", ["toy", "true"])
+@pytest.mark.parametrize("aten", [False, True])
+def test_improved_rnn(tag, aten):
+    g = load_golden("improved_rnn_" + tag)
+    P = {"gru." + k[len("param/module."):]: t(v).requires_grad_(True) for k, v in g.items() if k.startswith("param/")}
+    x = t(g["x"]).requires_grad_(True)
+    lengths = t(g["lengths"])
+    out = R.improved_rnn(x, lengths, P, "gru.", aten=aten)
+    si, ui = R.gru_sort_indices(lengths)
+    assert np.array_equal(si.numpy(), g["sorted_indices"])  # bit-exact index work
+    assert np.array_equal(ui.numpy(), g["unsorted_indices"])
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], atol=2e-6, rtol=0)
+    out.backward(t(g["gout"]))
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], atol=1e-5, rtol=1e-4)
+    for k, p in P.items():
+        np.testing.assert_allclose(p.grad.numpy(), g["grad/module." + k[len("gru."):]], atol=2e-5, rtol=1e-4)
+
+
+def test_sort_ties_not_stable():
+    g = load_golden("sort_ties")
+    si, ui = R.gru_sort_indices(t(g["lengths"]))
+    assert np.array_equal(si.numpy(), g["sorted_indices"])
+    assert np.array_equal(ui.numpy(), g["unsorted_indices"])
+    stable = torch.sort(t(g["lengths"]), descending=True, stable=True)[1]
+    assert not np.array_equal(stable.numpy(), g["sorted_indices"]), "fixture no longer shows the non-stable tie order"
+
+
+def _run(name, aten=False):
+    g = load_golden(name)
+    B, V, ronly, pseed, bseed, full_pad, vocab = [int(v) for v in g["meta"]]
+    P = make_param_state(pseed, 50, vocab, V, bool(ronly), m_scale=float(g["m_scale"]))
+    for k, p in P.items():
+        if k != "embedding.weight":
+            p.requires_grad_(True)
+    batch = make_batch(bseed, B, vocab, V, review_net_only=bool(ronly), full_pad=bool(full_pad))
+    masks = None
+    if "drop_mask0" in g:
+        masks = [t(g["drop_mask0"]).float(), t(g["drop_mask1"]).float()]
+    keep = {}
+    pred, loss = R.umpr_forward(P, batch, review_net_only=bool(ronly), dropout_masks=masks, aten=aten, keep=keep)
+    loss.backward()
+    return g, P, pred, loss, keep
+
+
+def _check(g, P, pred, loss, keep, fwd_tol=2e-6):
+    np.testing.assert_allclose(pred.detach().numpy(), g["prediction"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(loss.item(), g["loss"], atol=1e-5, rtol=1e-6)
+    for k in ("gru_u", "gru_i", "soft_u", "soft_i", "atte_u", "atte_i", "senti_u", "senti_i", "review_repr",
+              "c_u", "c_i", "prefer_pos", "prefer_neg", "pos_match", "neg_match", "final_pos", "final_neg", "vgg_out"):
+        if k in g:
+            np.testing.assert_allclose(keep[k].detach().numpy(), g[k], atol=2e-5, rtol=1e-5, err_msg=k)
+    for k, p in P.items():
+        if "grad/" + k in g:
+            ref = g["grad/" + k]
+            scale = max(1e-6, float(np.abs(ref).max()))
+            np.testing.assert_allclose(p.grad.numpy(), ref, atol=1e-4 * scale + 1e-7, rtol=1e-3, err_msg=k)
+        elif "gradstat/" + k in g:
+            st = g["gradstat/" + k]
+            flat = p.grad.reshape(-1)
+            np.testing.assert_allclose(flat[:: int(st[3])].numpy(), g["gradsample/" + k],
+                                       atol=1e-4 * float(np.abs(g["gradsample/" + k]).max()) + 1e-9, rtol=1e-3, err_msg=k)
+            np.testing.assert_allclose(flat.double().pow(2).sum().sqrt().item(), st[2], rtol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["umpr_r_B4", "umpr_r_B4_soft", "umpr_r_B3_fullpad"])
+@pytest.mark.parametrize("aten", [False, True])
+def test_umpr_r(name, aten):
+    _check(*_run(name, aten))
+
+
+@pytest.mark.parametrize("name", ["umpr_full_V1_B2", "umpr_full_V1_B2_randnM", "umpr_full_V4_B2", "umpr_full_V1_B2_drop"])
+def test_umpr_full(name):
+    _check(*_run(name, aten=True))
+
+
+def test_adam_trajectory():
+    g = load_golden("adam_umpr_r")
+    P = make_param_state(31, 50, 1000, 1, True, m_scale=0.05)
+    for k, p in P.items():
+        if k != "embedding.weight":
+            p.requires_grad_(True)
+    opt = R.adam_reference(P, float(g["lr"]), float(g["l2"]))
+    sch = torch.optim.lr_scheduler.ExponentialLR(opt, 0.99)
+    for step in range(3):
+        batch = make_batch(500 + step, 4, 1000, review_net_only=True)
+        _, loss = R.umpr_forward(P, batch, review_net_only=True, aten=True)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - g["losses"][step]) < 1e-5
+        if step == 0:
+            sch.step()
+    for k, p in P.items():
+        if "param/" + k in g:
+            np.testing.assert_allclose(p.detach().numpy(), g["param/" + k], atol=2e-6, rtol=1e-5, err_msg=k)
