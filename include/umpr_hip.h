@@ -1,0 +1,170 @@
+/* libumpr_hip.so - C ABI of the MI355X-native UMPR hot path.
+ *
+ * The reference (iamwinter/UMPR) has no FFI layer: its hot path is the Python nn.Module API of src/model.py
+ * (UMPR.__init__ model.py:233-255, UMPR.forward model.py:257-278) and all arithmetic runs inside torch ATen /
+ * torchvision.  This header is the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md): each
+ * entry point replaces the torch ops of the cited reference lines with hand-written gfx950 kernels.
+ *
+ * Conventions: every pointer is DEVICE memory owned by the caller (plain pointers and sizes, no torch types);
+ * fp32 unless noted; token ids are int64 (the reference's LongTensor); lengths / permutations are int32 arrays the
+ * host computes (the reference keeps lengths on the host too, model.py:18); `stream` is a hipStream_t passed as
+ * void*; workspaces come from the caller (size queries below) - the library never allocates or frees.
+ * Return value: 0 = ok, <0 = error (message: umpr_last_error(), thread-local).  Hidden sizes are the reference's
+ * configuration constants: gru_size 64 (2u = 128), self_atte_size 64 (config.py:34-35).
+ */
+#ifndef UMPR_HIP_H
+#define UMPR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* umpr_version(void);
+const char* umpr_last_error(void);
+/* name of device `dev`, number of CUs, bytes of HBM; used by bench.py to print what it ran on */
+int umpr_device_info(int dev, char* name, int name_len, int* compute_units, size_t* hbm_bytes);
+
+/* ---- generic fp32 MFMA GEMM: C = act(alpha * op(A) op(B) + bias + (accumulate ? C : 0)) --------------------
+ * Replaces torch.mm/addmm/Linear call sites on the path (model.py:50,75,120,154-155,167-168; VGG classifier).
+ * op(A)(m,k) = transA ? A[k*lda+m] : A[m*lda+k];  op(B)(k,n) = transB ? B[n*ldb+k] : B[k*ldb+n].
+ * bias_mode: 0 none, 1 bias[n], 2 bias[m].  act: 0 none, 1 relu, 2 tanh, 3 sigmoid.
+ * ws/ws_bytes: optional split-K workspace (used when the grid would not fill the GPU). */
+int umpr_gemm_f32(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C, long ldc,
+                  int M, int N, int K, const float* bias, int bias_mode, int act, int accumulate, float alpha,
+                  float* ws, size_t ws_bytes, void* stream);
+
+/* ---- K1-K3: embedding lookup + bidirectional packed GRU + the reference's double un-sort ---------------------
+ * Replaces nn.Embedding (model.py:262-264) + ImprovedRnn.forward (model.py:12-21) for one review tensor.
+ * ids [N*L] int64; emb [vocab][E]; GRU weights in nn.GRU layout (gate order r,z,n): w_ih [192][E], w_hh [192][64],
+ * b_ih/b_hh [192], forward direction then "_reverse".  lengths [N]; order [N] = sorted_indices (descending length,
+ * the tie order torch.sort produced); dst_row [N]: input row n lands in output row dst_row[n] (= sorted_indices[n]
+ * for the reference's semantics).  out [N][L][128] (zeros past each length).  saved [2][N][L][4][64] (gates for
+ * backward) or NULL for inference. */
+size_t umpr_embed_gru_bidir_ws_bytes(int N, int L, int E);
+int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,
+                             const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
+                             const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                             const int32_t* lengths, const int32_t* order, const int32_t* dst_row, int N, int L,
+                             float* out, float* saved, float* ws, size_t ws_bytes, void* stream);
+/* dout [N][L][128]; d* receive the parameter gradients (overwritten).  The embedding table is frozen
+ * (nn.Embedding.from_pretrained, model.py:237) so no gradient is produced for it. */
+int umpr_embed_gru_bidir_bwd(const int64_t* ids, const float* emb, int E,
+                             const float* w_hh_f, const float* w_hh_r,
+                             const int32_t* lengths, const int32_t* order, const int32_t* dst_row, int N, int L,
+                             const float* dout, const float* out, const float* saved,
+                             float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
+                             float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
+                             float* ws, size_t ws_bytes, void* stream);
+
+/* ---- K4-K5: R-Net co-attention (model.py:50-55) --------------------------------------------------------------
+ * Gu, Gi [B][SL][128]; M [128][128].  Outputs soft_u/soft_i [B][SL], atte_u/atte_i rows of 128 written at
+ * atte_x + b*ld_x (lets the caller place them inside the [B][256] concat of model.py:166-167).
+ * Saved for backward: T [B][SL][128], colmax/rowmax [B][SL], argcol/argrow [B][SL] int32. */
+size_t umpr_coattention_fwd_ws_bytes(int B, int SL);
+int umpr_coattention_fwd(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
+                         float* soft_i, float* atte_u, long ld_u, float* atte_i, long ld_i, float* colmax,
+                         int32_t* argcol, float* rowmax, int32_t* argrow, float* ws, size_t ws_bytes, void* stream);
+size_t umpr_coattention_bwd_ws_bytes(int B, int SL);
+int umpr_coattention_bwd(const float* Gu, const float* Gi, const float* M, const float* T, const float* soft_u,
+                         const float* soft_i, const float* colmax, const int32_t* argcol, const float* rowmax,
+                         const int32_t* argrow, const float* d_atte_u, long ld_du, const float* d_atte_i, long ld_di,
+                         const float* d_soft_u, const float* d_soft_i, int B, int SL, float* dGu, float* dGi,
+                         float* dM, int accumulate /* add onto dGu,dGi */, float* ws, size_t ws_bytes, void* stream);
+
+/* ---- K6: S-Net (model.py:71-81) ------------------------------------------------------------------------------
+ * X [B][S][L][128]; Ms [64][128]; Ws [64]; word_soft [B][S][wl] (wl = L for soft_u/soft_i, V for view_p).
+ * Outputs: self_atte [B][S][128], senti rows at senti + b*ld_senti.  Saved: U [B][S][L][64], P [B][S][L], wsum [B][S]. */
+int umpr_snet_fwd(const float* X, const float* Ms, const float* Ws, const float* word_soft, int wl, int B, int S,
+                  int L, float* U, float* P, float* wsum, float* self_atte, float* senti, long ld_senti, void* stream);
+size_t umpr_snet_bwd_ws_bytes(int B, int S, int L);
+int umpr_snet_bwd(const float* X, const float* Ms, const float* Ws, const float* U, const float* P, const float* wsum,
+                  const float* self_atte, const float* d_senti, long ld_ds, const float* d_self_atte /*or NULL*/,
+                  int B, int S, int L, int wl, float* dX, float* dMs, float* dWs, float* d_word_soft /*or NULL*/,
+                  float* ws, size_t ws_bytes, void* stream);
+
+/* ---- K7: ReviewNet merge tanh(W_u [atte_u;senti_u] + W_i [atte_i;senti_i]) (model.py:166-168) ----------------
+ * repr_u, repr_i [B][256]; W_u, W_i [128][256]; out [B][128]. */
+int umpr_review_merge_fwd(const float* repr_u, const float* repr_i, const float* W_u, const float* W_i, int B,
+                          float* out, void* stream);
+size_t umpr_review_merge_bwd_ws_bytes(int B);
+int umpr_review_merge_bwd(const float* repr_u, const float* repr_i, const float* W_u, const float* W_i,
+                          const float* out, const float* d_out, int B, float* d_repr_u, float* d_repr_i, float* dW_u,
+                          float* dW_i, float* ws, size_t ws_bytes, void* stream);
+
+/* ---- K8: C-Net head: Conv1d(128->KC,k=KS,pad)+ReLU+max_L, Linear(KC->V)+Sigmoid, threshold, sum p^2
+ * (model.py:118-125).  X [B][S][L][128]; Wc [KC][128][KS]; Wl [V][KC].  Outputs view_p [B][S][V], final [B][V].
+ * Saved: Y [B][S][L][KC], cmax [B][S][KC], argl int32 [B][S][KC], sp [B][S][V]. */
+size_t umpr_cnet_head_fwd_ws_bytes(int B, int S, int L, int KS);
+int umpr_cnet_head_fwd(const float* X, const float* Wc, const float* bc, const float* Wl, const float* bl, float thr,
+                       int B, int S, int L, int KC, int KS, int V, float* Y, float* cmax, int32_t* argl, float* sp,
+                       float* view_p, float* final_, float* ws, size_t ws_bytes, void* stream);
+size_t umpr_cnet_head_bwd_ws_bytes(int B, int S, int L, int KC, int KS, int V);
+int umpr_cnet_head_bwd(const float* X, const float* Wc, const float* Wl, const float* cmax, const int32_t* argl,
+                       const float* sp, const float* view_p, const float* d_final /*or NULL*/,
+                       const float* d_view_p /*or NULL*/, int B, int S, int L, int KC, int KS, int V, float* dX,
+                       int accumulate_dX, int accumulate_w /* add onto dX / the weight grads */, float* dWc,
+                       float* dbc, float* dWl, float* dbl, float* ws, size_t ws_bytes, void* stream);
+
+/* ---- K9: control gate incl. SS-Net (model.py:142-143,186-197) ------------------------------------------------ */
+int umpr_control_gate_fwd(const float* self_atte, const float* w, const float* bias, const float* view_p,
+                          const float* c_out, int B, int S, int V, float* senti, float* view_score,
+                          float* prefer_pos, float* prefer_neg, void* stream);
+size_t umpr_control_gate_bwd_ws_bytes(int B);
+int umpr_control_gate_bwd(const float* self_atte, const float* w, const float* view_p, const float* c_out,
+                          const float* senti, const float* view_score, const float* d_prefer_pos,
+                          const float* d_prefer_neg, int B, int S, int V, float* d_self_atte, float* d_view_p,
+                          float* d_c_out, float* dw, float* db, float* ws, size_t ws_bytes, void* stream);
+
+/* ---- K10: VGG16-D feature extractor (torchvision.models.vgg16, call site model.py:204-207,217) ---------------
+ * images [n][3][224][224]; params: 32 pointers = 13 x (conv weight [Cout][Cin][3][3], bias) then 3 x (fc weight
+ * [out][in], bias) in torchvision order.  acts: activation arena (umpr_vgg16_act_bytes), kept for backward.
+ * train!=0 applies Dropout(0.5) after fc1/fc2 with a counter-hash mask from `seed`; use_masks!=0 reads the caller's
+ * keep-masks (uint8 [2][n][4096] in `masks`) instead (parity tests).  out [n][1000]. */
+size_t umpr_vgg16_act_bytes(int n_img);
+size_t umpr_vgg16_fwd_ws_bytes(int n_img);
+size_t umpr_vgg16_ws_bytes(int n_img); /* backward workspace */
+int umpr_vgg16_fwd(const float* images, const float* const* params, int n_img, int train, int use_masks,
+                   uint64_t seed, float* acts, uint8_t* masks, float* out, float* ws, size_t ws_bytes, void* stream);
+/* grads: 32 pointers matching params (overwritten).  train != 0 <=> dropout was applied in the forward pass
+ * (train or use_masks). */
+int umpr_vgg16_bwd(const float* images, const float* const* params, int n_img, int train, const float* acts,
+                   const uint8_t* masks, const float* d_out, float* const* grads, float* ws, size_t ws_bytes,
+                   void* stream);
+/* per-layer entry points (also what the composite calls) */
+int umpr_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
+                     int Cout, int relu, void* stream);
+/* dx = conv_transpose(dy, w) [* (mask_src > 0)]; wt: scratch [Cin][Cout*9] */
+int umpr_conv3x3_bwd_data(const float* dy, const float* w, const float* mask_src /*or NULL*/, float* dx, int N,
+                          int Cin, int H, int W, int Cout, float* wt, void* stream);
+size_t umpr_conv3x3_bwd_weight_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int umpr_conv3x3_bwd_weight(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
+                            int Cout, float* ws, size_t ws_bytes, void* stream);
+int umpr_maxpool2_fwd(const float* x, float* y, long planes, int H, int W, void* stream);
+int umpr_maxpool2_bwd_relu(const float* x, const float* dy, float* dx, long planes, int H, int W, void* stream);
+
+/* ---- K11-K12: visual head + fusion + losses (model.py:218-228,267-277) ----------------------------------------
+ * V = 0 selects the review_net_only branch (model.py:267-269).  loss [3] = (loss, loss_r, loss_v). */
+int umpr_head_fwd(const float* rr, const float* c_u, const float* c_i, const float* prefer_pos,
+                  const float* prefer_neg, const float* vgg, const float* pos_v_emb, const float* neg_v_emb,
+                  const float* lin_w, const float* lin_b, const float* fus_w, const float* fus_b, const float* labels,
+                  float loss_v_rate, int B, int V, int P, float* pred, float* loss, float* z, float* img_emb,
+                  float* pos_match, float* neg_match, float* posneg_emb, void* stream);
+int umpr_head_bwd(const float* rr, const float* c_u, const float* c_i, const float* prefer_pos,
+                  const float* prefer_neg, const float* vgg, const float* pos_v_emb, const float* neg_v_emb,
+                  const float* lin_w, const float* fus_w, const float* labels, float loss_v_rate, int B, int V, int P,
+                  const float* pred, const float* z, const float* img_emb, const float* pos_match,
+                  const float* neg_match, const float* posneg_emb, const float* d_loss, const float* d_pred /*or NULL*/,
+                  float* d_rr, float* d_cu, float* d_ci, float* d_pp, float* d_pn, float* d_vgg, float* d_pos_v,
+                  float* d_neg_v, float* d_lin_w, float* d_lin_b, float* d_fus_w, float* d_fus_b, void* stream);
+
+/* ---- K13: Adam step with coupled L2, as torch.optim.Adam drives it in main.py:22-26,37 ----------------------
+ * One flat parameter segment: p,g,m,v [n]; step >= 1; grad_scale multiplies g first (1/world for data parallel). */
+int umpr_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, long step, double grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,61 @@
+"""The C-ABI library loads, exports every symbol include/umpr_hip.h declares, and the ctypes signature table in
+umpr_amd/_lib.py agrees with the header (no compute calls: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_header():
+    txt = open(os.path.join(ROOT, "include", "umpr_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([\w\s\*]+?)\b(umpr_\w+)\s*\(([^;{]*?)\)\s*;", txt):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3)
+        codes = ""
+        if args.strip() not in ("", "void"):
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    codes += "p"
+                elif "size_t" in a:
+                    codes += "z"
+                elif "uint64_t" in a:
+                    codes += "u"
+                elif re.search(r"\blong\b", a):
+                    codes += "l"
+                elif re.search(r"\bdouble\b", a):
+                    codes += "d"
+                elif re.search(r"\bfloat\b", a):
+                    codes += "f"
+                elif re.search(r"\bint\b", a):
+                    codes += "i"
+                else:
+                    raise AssertionError(f"unparsed argument {a!r} of {name}")
+        rc = "s" if "char" in ret else ("z" if "size_t" in ret else "i")
+        protos[name] = (codes, rc)
+    return protos
+
+
+def test_signature_table_matches_header():
+    from umpr_amd._lib import SIGNATURES
+    protos = parse_header()
+    assert len(protos) >= 35
+    assert set(protos) == set(SIGNATURES), set(protos) ^ set(SIGNATURES)
+    for name, sig in protos.items():
+        assert SIGNATURES[name] == sig, (name, SIGNATURES[name], sig)
+
+
+def test_library_exports_every_declared_symbol():
+    path = os.path.join(ROOT, "umpr_amd", "libumpr_hip.so")
+    if not os.path.exists(path):
+        import __graft_entry__ as g
+        g.build()
+    cdll = ctypes.CDLL(path)
+    for name in parse_header():
+        assert hasattr(cdll, name), f"{name} declared in include/umpr_hip.h but not exported"
+    cdll.umpr_version.restype = ctypes.c_char_p
+    assert b"gfx950" in cdll.umpr_version()

@@ -1,0 +1,130 @@
+"""ctypes binding of libumpr_hip.so (C ABI in include/umpr_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is raised
+(the product path never routes through oracle/ or through torch arithmetic).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libumpr_hip.so")
+
+_T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "z": ctypes.c_size_t, "f": ctypes.c_float,
+      "d": ctypes.c_double, "u": ctypes.c_uint64}
+
+# name -> (argument codes, return code).  p pointer, i int, l long, z size_t, f float, d double, u uint64.
+SIGNATURES = {
+    "umpr_version": ("", "s"),
+    "umpr_last_error": ("", "s"),
+    "umpr_device_info": ("ipipp", "i"),
+    "umpr_gemm_f32": ("pliplipliiipiiifpzp", "i"),
+    "umpr_embed_gru_bidir_ws_bytes": ("iii", "z"),
+    "umpr_embed_gru_bidir_fwd": ("ppipppppppppppiipppzp", "i"),
+    "umpr_embed_gru_bidir_bwd": ("ppipppppiippppppppppppzp", "i"),
+    "umpr_coattention_fwd_ws_bytes": ("ii", "z"),
+    "umpr_coattention_fwd": ("pppiipppplplpppppzp", "i"),
+    "umpr_coattention_bwd_ws_bytes": ("ii", "z"),
+    "umpr_coattention_bwd": ("ppppppppppplplppiipppipzp", "i"),
+    "umpr_snet_fwd": ("ppppiiiippppplp", "i"),
+    "umpr_snet_bwd_ws_bytes": ("iii", "z"),
+    "umpr_snet_bwd": ("pppppppplpiiiipppppzp", "i"),
+    "umpr_review_merge_fwd": ("ppppipp", "i"),
+    "umpr_review_merge_bwd_ws_bytes": ("i", "z"),
+    "umpr_review_merge_bwd": ("ppppppipppppzp", "i"),
+    "umpr_cnet_head_fwd_ws_bytes": ("iiii", "z"),
+    "umpr_cnet_head_fwd": ("pppppfiiiiiipppppppzp", "i"),
+    "umpr_cnet_head_bwd_ws_bytes": ("iiiiii", "z"),
+    "umpr_cnet_head_bwd": ("pppppppppiiiiiipiipppppzp", "i"),
+    "umpr_control_gate_fwd": ("pppppiiippppp", "i"),
+    "umpr_control_gate_bwd_ws_bytes": ("i", "z"),
+    "umpr_control_gate_bwd": ("ppppppppiiippppppzp", "i"),
+    "umpr_vgg16_act_bytes": ("i", "z"),
+    "umpr_vgg16_fwd_ws_bytes": ("i", "z"),
+    "umpr_vgg16_ws_bytes": ("i", "z"),
+    "umpr_vgg16_fwd": ("ppiiiuppppzp", "i"),
+    "umpr_vgg16_bwd": ("ppiipppppzp", "i"),
+    "umpr_conv3x3_fwd": ("ppppiiiiiip", "i"),
+    "umpr_conv3x3_bwd_data": ("ppppiiiiipp", "i"),
+    "umpr_conv3x3_bwd_weight_ws_bytes": ("iiiii", "z"),
+    "umpr_conv3x3_bwd_weight": ("ppppiiiiipzp", "i"),
+    "umpr_maxpool2_fwd": ("ppliip", "i"),
+    "umpr_maxpool2_bwd_relu": ("pppliip", "i"),
+    "umpr_head_fwd": ("pppppppppppppfiiipppppppp", "i"),
+    "umpr_head_bwd": ("pppppppppppfiiippppppppppppppppppppp", "i"),
+    "umpr_adam_step": ("ppppldddddldp", "i"),
+}
+
+
+class UmprHipError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise UmprHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C umpr_amd/csrc`).  There is no CPU fallback.")
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.fn = {}
+        for name, (args, ret) in SIGNATURES.items():
+            f = getattr(self.cdll, name)
+            f.argtypes = [_T[c] for c in args]
+            f.restype = {"i": ctypes.c_int, "z": ctypes.c_size_t, "s": ctypes.c_char_p}[ret]
+            self.fn[name] = f
+
+    def last_error(self) -> str:
+        return self.fn["umpr_last_error"]().decode()
+
+    def call(self, name, *args):
+        """Call an int-returning entry point; tensors become device pointers; raises on error."""
+        conv = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                conv.append(a.data_ptr())
+            elif a is None:
+                conv.append(None)
+            else:
+                conv.append(a)
+        rc = self.fn[name](*conv)
+        if rc != 0:
+            raise UmprHipError(f"{name} failed (rc={rc}): {self.last_error()}")
+
+    def size(self, name, *args) -> int:
+        return int(self.fn[name](*args))
+
+
+_LIB = None
+
+
+def lib() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Workspace:
+    """One growing scratch buffer per device.  Ops on one stream are serialised, so they can share it; nothing in
+    it is live between two C-ABI calls."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes: int, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() * 4 < nbytes:
+            buf = None
+            cls._bufs[key] = None
+            n = (int(nbytes * 1.1) + 1023) // 4
+            buf = torch.empty(n, dtype=torch.float32, device=device)
+            cls._bufs[key] = buf
+        return buf

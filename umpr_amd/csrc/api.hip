@@ -1,0 +1,437 @@
+// extern "C" entry points of libumpr_hip.so (declared in include/umpr_hip.h) and the composite ops they launch.
+#include <math.h>
+#include <stdarg.h>
+
+#include "../../include/umpr_hip.h"
+#include "umpr_common.h"
+#include "umpr_internal.h"
+
+static thread_local char g_err[512] = "";
+void umpr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+constexpr int D = 128, H = 64, G3 = 192, AT = 64;
+
+// VGG16-D geometry (torchvision cfg "D"): 13 convs in 5 blocks, a 2x2 max pool after each block
+constexpr int kConvPerBlock[5] = {2, 3 - 1, 3, 3, 3};  // 2,2,3,3,3
+constexpr int kBlockCh[5] = {64, 128, 256, 512, 512};
+constexpr int kFc[3][2] = {{25088, 4096}, {4096, 4096}, {4096, 1000}};
+
+struct VggLayout {
+  // feature activations in order: for each block, conv outputs (post-ReLU) then the pooled output
+  size_t conv_off[13]; size_t pool_off[5];
+  int conv_cin[13], conv_cout[13], conv_hw[13], conv_block[13];
+  size_t fc_off[2];     // ReLU outputs of fc1, fc2 ([n][4096])
+  size_t drop_off[2];   // dropout outputs
+  size_t total;         // floats
+};
+VggLayout vgg_layout(int n) {
+  VggLayout L;
+  size_t off = 0;
+  int cin = 3, hw = 224, ci = 0;
+  for (int b = 0; b < 5; ++b) {
+    for (int j = 0; j < kConvPerBlock[b]; ++j) {
+      L.conv_cin[ci] = cin; L.conv_cout[ci] = kBlockCh[b]; L.conv_hw[ci] = hw; L.conv_block[ci] = b;
+      L.conv_off[ci] = off;
+      off += (size_t)n * kBlockCh[b] * hw * hw;
+      cin = kBlockCh[b];
+      ++ci;
+    }
+    hw /= 2;
+    L.pool_off[b] = off;
+    off += (size_t)n * kBlockCh[b] * hw * hw;
+  }
+  for (int j = 0; j < 2; ++j) { L.fc_off[j] = off; off += (size_t)n * 4096; }
+  for (int j = 0; j < 2; ++j) { L.drop_off[j] = off; off += (size_t)n * 4096; }
+  L.total = off;
+  return L;
+}
+}  // namespace
+
+extern "C" {
+
+const char* umpr_version(void) { return "umpr_hip 0.1 (gfx950)"; }
+const char* umpr_last_error(void) { return g_err; }
+
+int umpr_device_info(int dev, char* name, int name_len, int* compute_units, size_t* hbm_bytes) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { umpr_set_error("device_info: no device %d", dev); return -1; }
+  if (name && name_len > 0) { strncpy(name, prop.name, name_len - 1); name[name_len - 1] = 0; }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return 0;
+}
+
+int umpr_gemm_f32(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C, long ldc,
+                  int M, int N, int K, const float* bias, int bias_mode, int act, int accumulate, float alpha,
+                  float* ws, size_t ws_bytes, void* stream) {
+  UmprGemm g;
+  g.A = A; g.lda = lda; g.transA = transA != 0; g.B = B; g.ldb = ldb; g.transB = transB != 0; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.bias = bias; g.bias_mode = bias_mode; g.act = act; g.accumulate = accumulate != 0;
+  g.alpha = alpha; g.split_k = ws ? 0 : 1; g.ws = ws; g.ws_bytes = ws_bytes;
+  return umpr_gemm(g, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ GRU
+size_t umpr_embed_gru_bidir_ws_bytes(int N, int L, int E) {
+  const size_t tiles = umpr_gru_tiles(N);
+  // gx / dgx [N*L*384] + dWhh slabs + bias slabs + split-K slab for dW_ih
+  return ((size_t)N * L * 384 + tiles * 2 * G3 * H + tiles * 2 * 2 * G3 + (size_t)128 * G3 * E) * sizeof(float);
+}
+
+int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,
+                             const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
+                             const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                             const int32_t* lengths, const int32_t* order, const int32_t* dst_row, int N, int L,
+                             float* out, float* saved, float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(N > 0 && L > 0 && E > 0, "embed_gru: bad shape N=%d L=%d E=%d", N, L, E);
+  UMPR_REQUIRE(ws_bytes >= (size_t)N * L * 384 * sizeof(float), "embed_gru: workspace too small");
+  float* gx = ws;
+  for (int d = 0; d < 2; ++d) {  // gx[:, d*192:(d+1)*192] = emb[ids] W_ih^T + b_ih
+    UmprGemm g;
+    g.A = emb; g.lda = E; g.gatherA = ids; g.B = d ? w_ih_r : w_ih_f; g.ldb = E; g.transB = true;
+    g.C = gx + d * G3; g.ldc = 384; g.M = N * L; g.N = G3; g.K = E;
+    g.bias = d ? b_ih_r : b_ih_f; g.bias_mode = 1;
+    if (int rc = umpr_gemm(g, S(stream))) return rc;
+  }
+  return umpr_gru_recurrent_fwd(gx, w_hh_f, b_hh_f, w_hh_r, b_hh_r, lengths, order, dst_row, out, saved, N, L, S(stream));
+}
+
+int umpr_embed_gru_bidir_bwd(const int64_t* ids, const float* emb, int E, const float* w_hh_f, const float* w_hh_r,
+                             const int32_t* lengths, const int32_t* order, const int32_t* dst_row, int N, int L,
+                             const float* dout, const float* out, const float* saved,
+                             float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
+                             float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
+                             float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_embed_gru_bidir_ws_bytes(N, L, E), "embed_gru_bwd: workspace too small");
+  const int tiles = umpr_gru_tiles(N);
+  float* dgx = ws;
+  float* wslab = dgx + (size_t)N * L * 384;
+  float* bslab = wslab + (size_t)tiles * 2 * G3 * H;
+  float* kslab = bslab + (size_t)tiles * 2 * 2 * G3;
+  if (int rc = umpr_gru_bptt(dout, out, saved, w_hh_f, w_hh_r, lengths, order, dst_row, dgx, wslab, bslab, N, L, S(stream)))
+    return rc;
+  float* dwhh[2] = {dw_hh_f, dw_hh_r};
+  float* dbih[2] = {db_ih_f, db_ih_r};
+  float* dbhh[2] = {db_hh_f, db_hh_r};
+  float* dwih[2] = {dw_ih_f, dw_ih_r};
+  for (int d = 0; d < 2; ++d) {
+    if (int rc = umpr_colsum_rows(wslab + (size_t)d * G3 * H, tiles, G3 * H, 2 * G3 * H, dwhh[d], 0, S(stream))) return rc;
+    if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3, tiles, G3, 4 * G3, dbih[d], 0, S(stream))) return rc;
+    if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3 + G3, tiles, G3, 4 * G3, dbhh[d], 0, S(stream))) return rc;
+    UmprGemm g;  // dW_ih[192][E] = dgx[:, d]^T emb[ids]
+    g.A = dgx + d * G3; g.lda = 384; g.transA = true; g.B = emb; g.ldb = E; g.gatherB = ids;
+    g.C = dwih[d]; g.ldc = E; g.M = G3; g.N = E; g.K = N * L; g.split_k = 0; g.ws = kslab;
+    g.ws_bytes = (size_t)128 * G3 * E * sizeof(float);
+    if (int rc = umpr_gemm(g, S(stream))) return rc;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ co-attention
+size_t umpr_coattention_fwd_ws_bytes(int B, int SL) { return umpr_coattn_fwd_ws_bytes(B, SL); }
+int umpr_coattention_fwd(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
+                         float* soft_i, float* atte_u, long ld_u, float* atte_i, long ld_i, float* colmax,
+                         int32_t* argcol, float* rowmax, int32_t* argrow, float* ws, size_t ws_bytes, void* stream) {
+  return umpr_coattn_fwd_impl(Gu, Gi, M, B, SL, T, soft_u, soft_i, atte_u, ld_u, atte_i, ld_i, colmax, argcol, rowmax,
+                              argrow, ws, ws_bytes, S(stream));
+}
+size_t umpr_coattention_bwd_ws_bytes(int B, int SL) { return umpr_coattn_bwd_ws_bytes(B, SL); }
+int umpr_coattention_bwd(const float* Gu, const float* Gi, const float* M, const float* T, const float* soft_u,
+                         const float* soft_i, const float* colmax, const int32_t* argcol, const float* rowmax,
+                         const int32_t* argrow, const float* d_atte_u, long ld_du, const float* d_atte_i, long ld_di,
+                         const float* d_soft_u, const float* d_soft_i, int B, int SL, float* dGu, float* dGi,
+                         float* dM, int accumulate, float* ws, size_t ws_bytes, void* stream) {
+  return umpr_coattn_bwd_impl(Gu, Gi, M, T, soft_u, soft_i, colmax, argcol, rowmax, argrow, d_atte_u, ld_du, d_atte_i,
+                              ld_di, d_soft_u, d_soft_i, B, SL, dGu, dGi, dM, accumulate, ws, ws_bytes, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ S-Net
+int umpr_snet_fwd(const float* X, const float* Ms, const float* Ws, const float* word_soft, int wl, int B, int S_,
+                  int L, float* U, float* P, float* wsum, float* self_atte, float* senti, long ld_senti, void* stream) {
+  return umpr_snet_fwd_impl(X, Ms, Ws, word_soft, wl, B, S_, L, U, P, wsum, self_atte, senti, ld_senti, S(stream));
+}
+size_t umpr_snet_bwd_ws_bytes(int B, int S_, int L) { return umpr_snet_bwd_ws_bytes_impl(B, S_, L); }
+int umpr_snet_bwd(const float* X, const float* Ms, const float* Ws, const float* U, const float* P, const float* wsum,
+                  const float* self_atte, const float* d_senti, long ld_ds, const float* d_self_atte, int B, int S_,
+                  int L, int wl, float* dX, float* dMs, float* dWs, float* d_word_soft, float* ws, size_t ws_bytes,
+                  void* stream) {
+  return umpr_snet_bwd_impl(X, Ms, Ws, U, P, wsum, self_atte, d_senti, ld_ds, d_self_atte, B, S_, L, wl, dX, dMs, dWs,
+                            d_word_soft, ws, ws_bytes, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ merge
+int umpr_review_merge_fwd(const float* repr_u, const float* repr_i, const float* W_u, const float* W_i, int B,
+                          float* out, void* stream) {
+  UmprGemm g;
+  g.A = repr_u; g.lda = 2 * D; g.B = W_u; g.ldb = 2 * D; g.transB = true; g.C = out; g.ldc = D; g.M = B; g.N = D; g.K = 2 * D;
+  if (int rc = umpr_gemm(g, S(stream))) return rc;
+  g.A = repr_i; g.B = W_i; g.accumulate = true; g.act = UMPR_ACT_TANH;
+  return umpr_gemm(g, S(stream));
+}
+size_t umpr_review_merge_bwd_ws_bytes(int B) { return (size_t)B * D * sizeof(float); }
+int umpr_review_merge_bwd(const float* repr_u, const float* repr_i, const float* W_u, const float* W_i,
+                          const float* out, const float* d_out, int B, float* d_repr_u, float* d_repr_i, float* dW_u,
+                          float* dW_i, float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_review_merge_bwd_ws_bytes(B), "review_merge_bwd: workspace too small");
+  float* dpre = ws;
+  if (int rc = umpr_tanh_bwd(out, d_out, dpre, (long)B * D, S(stream))) return rc;
+  const float* reprs[2] = {repr_u, repr_i};
+  const float* Wm[2] = {W_u, W_i};
+  float* drepr[2] = {d_repr_u, d_repr_i};
+  float* dW[2] = {dW_u, dW_i};
+  for (int q = 0; q < 2; ++q) {
+    UmprGemm g;  // d_repr = dpre W
+    g.A = dpre; g.lda = D; g.B = Wm[q]; g.ldb = 2 * D; g.C = drepr[q]; g.ldc = 2 * D; g.M = B; g.N = 2 * D; g.K = D;
+    if (int rc = umpr_gemm(g, S(stream))) return rc;
+    UmprGemm h;  // dW = dpre^T repr
+    h.A = dpre; h.lda = D; h.transA = true; h.B = reprs[q]; h.ldb = 2 * D; h.C = dW[q]; h.ldc = 2 * D; h.M = D;
+    h.N = 2 * D; h.K = B;
+    if (int rc = umpr_gemm(h, S(stream))) return rc;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ C-Net head
+size_t umpr_cnet_head_fwd_ws_bytes(int B, int S_, int L, int KS) { return umpr_cnet_fwd_ws_bytes(B, S_, L, KS); }
+int umpr_cnet_head_fwd(const float* X, const float* Wc, const float* bc, const float* Wl, const float* bl, float thr,
+                       int B, int S_, int L, int KC, int KS, int V, float* Y, float* cmax, int32_t* argl, float* sp,
+                       float* view_p, float* final_, float* ws, size_t ws_bytes, void* stream) {
+  return umpr_cnet_head_fwd_impl(X, Wc, bc, Wl, bl, thr, B, S_, L, KC, KS, V, Y, cmax, argl, sp, view_p, final_, ws,
+                                 ws_bytes, S(stream));
+}
+size_t umpr_cnet_head_bwd_ws_bytes(int B, int S_, int L, int KC, int KS, int V) {
+  return umpr_cnet_bwd_ws_bytes(B, S_, L, KC, KS, V);
+}
+int umpr_cnet_head_bwd(const float* X, const float* Wc, const float* Wl, const float* cmax, const int32_t* argl,
+                       const float* sp, const float* view_p, const float* d_final, const float* d_view_p, int B,
+                       int S_, int L, int KC, int KS, int V, float* dX, int accumulate_dX, int accumulate_w, float* dWc,
+                       float* dbc, float* dWl, float* dbl, float* ws, size_t ws_bytes, void* stream) {
+  return umpr_cnet_head_bwd_impl(X, Wc, Wl, cmax, argl, sp, view_p, d_final, d_view_p, B, S_, L, KC, KS, V, dX,
+                                 accumulate_dX, accumulate_w, dWc, dbc, dWl, dbl, ws, ws_bytes, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ gate
+int umpr_control_gate_fwd(const float* self_atte, const float* w, const float* bias, const float* view_p,
+                          const float* c_out, int B, int S_, int V, float* senti, float* view_score,
+                          float* prefer_pos, float* prefer_neg, void* stream) {
+  return umpr_gate_fwd_impl(self_atte, w, bias, view_p, c_out, B, S_, V, senti, view_score, prefer_pos, prefer_neg, S(stream));
+}
+size_t umpr_control_gate_bwd_ws_bytes(int B) { return umpr_gate_bwd_ws_bytes(B); }
+int umpr_control_gate_bwd(const float* self_atte, const float* w, const float* view_p, const float* c_out,
+                          const float* senti, const float* view_score, const float* d_prefer_pos,
+                          const float* d_prefer_neg, int B, int S_, int V, float* d_self_atte, float* d_view_p,
+                          float* d_c_out, float* dw, float* db, float* ws, size_t ws_bytes, void* stream) {
+  return umpr_gate_bwd_impl(self_atte, w, view_p, c_out, senti, view_score, d_prefer_pos, d_prefer_neg, B, S_, V,
+                            d_self_atte, d_view_p, d_c_out, dw, db, ws, ws_bytes, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ VGG16
+size_t umpr_vgg16_act_bytes(int n_img) { return vgg_layout(n_img).total * sizeof(float); }
+
+namespace {
+size_t vgg_scratch_bytes(int n) {
+  // largest of: conv wgrad slabs, split-K slabs of the small-batch classifier GEMMs
+  size_t slab = 0;
+  const VggLayout L = vgg_layout(n);
+  for (int i = 0; i < 13; ++i) {
+    const size_t b = umpr_conv3x3_wgrad_ws_bytes(n, L.conv_cin[i], L.conv_cout[i], L.conv_hw[i], L.conv_hw[i]);
+    if (b > slab) slab = b;
+  }
+  size_t fcs = (size_t)4 * n * 25088;
+  if ((size_t)16 * n * 4096 > fcs) fcs = (size_t)16 * n * 4096;
+  fcs *= sizeof(float);
+  return align_up(slab > fcs ? slab : fcs, 256);
+}
+constexpr size_t kWtFloats = (size_t)512 * 512 * 9;
+}  // namespace
+
+size_t umpr_vgg16_fwd_ws_bytes(int n_img) { return vgg_scratch_bytes(n_img); }
+
+size_t umpr_vgg16_ws_bytes(int n_img) {
+  // [gradient ping][gradient pong] (largest activation each) [flip-transposed weights][scratch]
+  const size_t big = (size_t)n_img * 64 * 224 * 224;
+  return (2 * big + kWtFloats) * sizeof(float) + vgg_scratch_bytes(n_img);
+}
+
+int umpr_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H_, int W,
+                     int Cout, int relu, void* stream) {
+  return umpr_conv3x3_igemm(x, w, bias, nullptr, y, N, Cin, H_, W, Cout, relu, S(stream));
+}
+int umpr_conv3x3_bwd_data(const float* dy, const float* w, const float* mask_src, float* dx, int N, int Cin, int H_,
+                          int W, int Cout, float* wt, void* stream) {
+  if (int rc = umpr_conv3x3_flip_transpose(w, wt, Cout, Cin, S(stream))) return rc;
+  return umpr_conv3x3_igemm(dy, wt, nullptr, mask_src, dx, N, Cout, H_, W, Cin, 0, S(stream));
+}
+size_t umpr_conv3x3_bwd_weight_ws_bytes(int N, int Cin, int Cout, int H_, int W) {
+  return umpr_conv3x3_wgrad_ws_bytes(N, Cin, Cout, H_, W);
+}
+int umpr_conv3x3_bwd_weight(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int H_, int W,
+                            int Cout, float* ws, size_t ws_bytes, void* stream) {
+  return umpr_conv3x3_wgrad(dy, x, dw, db, N, Cin, Cout, H_, W, 0, ws, ws_bytes, S(stream));
+}
+int umpr_maxpool2_fwd(const float* x, float* y, long planes, int H_, int W, void* stream) {
+  return umpr_maxpool2_fwd_impl(x, y, planes, H_, W, S(stream));
+}
+int umpr_maxpool2_bwd_relu(const float* x, const float* dy, float* dx, long planes, int H_, int W, void* stream) {
+  return umpr_maxpool2_bwd_relu_impl(x, dy, dx, planes, H_, W, S(stream));
+}
+
+int umpr_vgg16_fwd(const float* images, const float* const* params, int n, int train, int use_masks, uint64_t seed,
+                   float* acts, uint8_t* masks, float* out, float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(n > 0 && images && params && acts && out, "vgg16_fwd: bad arguments");
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_fwd_ws_bytes(n), "vgg16_fwd: workspace too small");
+  const VggLayout L = vgg_layout(n);
+  hipStream_t s = S(stream);
+  const float* x = images;
+  int ci = 0;
+  for (int b = 0; b < 5; ++b) {
+    for (int j = 0; j < kConvPerBlock[b]; ++j, ++ci) {
+      float* y = acts + L.conv_off[ci];
+      const int hw = L.conv_hw[ci];
+      if (int rc = umpr_conv3x3_igemm(x, params[2 * ci], params[2 * ci + 1], nullptr, y, n, L.conv_cin[ci], hw, hw,
+                                      L.conv_cout[ci], 1, s)) return rc;
+      x = y;
+    }
+    const int hw = L.conv_hw[ci - 1];
+    float* y = acts + L.pool_off[b];
+    if (int rc = umpr_maxpool2_fwd_impl(x, y, (long)n * kBlockCh[b], hw, hw, s)) return rc;
+    x = y;
+  }
+  // classifier; AdaptiveAvgPool2d(7) is the identity on the 7x7 map a 224x224 image produces
+  for (int j = 0; j < 3; ++j) {
+    UmprGemm g;
+    g.A = x; g.lda = kFc[j][0]; g.B = params[26 + 2 * j]; g.ldb = kFc[j][0]; g.transB = true;
+    g.C = j < 2 ? acts + L.fc_off[j] : out; g.ldc = kFc[j][1]; g.M = n; g.N = kFc[j][1]; g.K = kFc[j][0];
+    g.bias = params[27 + 2 * j]; g.bias_mode = 1; g.act = j < 2 ? UMPR_ACT_RELU : UMPR_ACT_NONE;
+    g.split_k = 0; g.ws = ws; g.ws_bytes = ws_bytes;
+    if (int rc = umpr_gemm(g, s)) return rc;
+    x = g.C;
+    if (j < 2 && (train || use_masks)) {
+      float* y = acts + L.drop_off[j];
+      if (int rc = umpr_dropout_fwd_impl(x, y, masks + (size_t)j * n * 4096, (long)n * 4096, 0.5f,
+                                         seed + 0x9E3779B97F4A7C15ULL * (j + 1), use_masks ? 0 : 1, s)) return rc;
+      x = y;
+    }
+  }
+  return 0;
+}
+
+int umpr_vgg16_bwd(const float* images, const float* const* params, int n, int train, const float* acts,
+                   const uint8_t* masks, const float* d_out, float* const* grads, float* ws, size_t ws_bytes,
+                   void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_ws_bytes(n), "vgg16_bwd: workspace too small (%zu < %zu)", ws_bytes,
+               umpr_vgg16_ws_bytes(n));
+  const VggLayout L = vgg_layout(n);
+  hipStream_t s = S(stream);
+  const size_t big = (size_t)n * 64 * 224 * 224;
+  float* gA = ws;
+  float* gB = ws + big;
+  float* wt = gB + big;
+  float* scratch = wt + kWtFloats;
+  const size_t slab_bytes = vgg_scratch_bytes(n);
+  // ---- classifier
+  const float* g = d_out;  // gradient w.r.t. the current layer's output
+  float* cur = gA; float* oth = gB;
+  for (int j = 2; j >= 0; --j) {
+    const int fin = kFc[j][0], fout = kFc[j][1];
+    const float* xin = j == 0 ? acts + L.pool_off[4]
+                              : ((train ? acts + L.drop_off[j - 1] : acts + L.fc_off[j - 1]));
+    if (j < 2) {
+      // g is d(dropout output or relu output); fold dropout mask and ReLU into gz
+      if (int rc = umpr_dropout_bwd_impl(g, train ? masks + (size_t)j * n * 4096 : nullptr, acts + L.fc_off[j], cur,
+                                         (long)n * 4096, 0.5f, s)) return rc;
+      g = cur; float* t = cur; cur = oth; oth = t;
+    }
+    UmprGemm w;  // dW[fout][fin] = g^T xin
+    w.A = g; w.lda = fout; w.transA = true; w.B = xin; w.ldb = fin; w.C = grads[26 + 2 * j]; w.ldc = fin;
+    w.M = fout; w.N = fin; w.K = n;
+    if (int rc = umpr_gemm(w, s)) return rc;
+    if (int rc = umpr_colsum_rows(g, n, fout, fout, grads[27 + 2 * j], 0, s)) return rc;
+    UmprGemm d;  // dx[n][fin] = g W
+    d.A = g; d.lda = fout; d.B = params[26 + 2 * j]; d.ldb = fin; d.C = cur; d.ldc = fin; d.M = n; d.N = fin; d.K = fout;
+    d.split_k = 0; d.ws = scratch; d.ws_bytes = slab_bytes;
+    if (int rc = umpr_gemm(d, s)) return rc;
+    g = cur; float* t = cur; cur = oth; oth = t;
+  }
+  // ---- features, last block first.  g = d(pool5 output)
+  int ci = 12;
+  for (int b = 4; b >= 0; --b) {
+    const int hw = L.conv_hw[ci];
+    // pool backward + ReLU mask of the conv output feeding it -> gradient w.r.t. the conv pre-activation
+    if (int rc = umpr_maxpool2_bwd_relu_impl(acts + L.conv_off[ci], g, cur, (long)n * kBlockCh[b], hw, hw, s)) return rc;
+    g = cur; { float* t = cur; cur = oth; oth = t; }
+    for (int j = kConvPerBlock[b] - 1; j >= 0; --j, --ci) {
+      const int cin = L.conv_cin[ci], cout = L.conv_cout[ci];
+      const float* xin = ci == 0 ? images : (j == 0 ? acts + L.pool_off[b - 1] : acts + L.conv_off[ci - 1]);
+      if (int rc = umpr_conv3x3_wgrad(g, xin, grads[2 * ci], grads[2 * ci + 1], n, cin, cout, hw, hw, 0, scratch,
+                                      slab_bytes, s)) return rc;
+      if (ci == 0) break;
+      if (int rc = umpr_conv3x3_flip_transpose(params[2 * ci], wt, cout, cin, s)) return rc;
+      // input came straight from a conv+ReLU (j > 0): mask by it; from a pool (j == 0): the pool backward masks
+      const float* mask = j > 0 ? xin : nullptr;
+      if (int rc = umpr_conv3x3_igemm(g, wt, nullptr, mask, cur, n, cout, hw, hw, cin, 0, s)) return rc;
+      g = cur; { float* t = cur; cur = oth; oth = t; }
+    }
+    if (ci == 0 && b == 0) break;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ head
+int umpr_head_fwd(const float* rr, const float* c_u, const float* c_i, const float* prefer_pos,
+                  const float* prefer_neg, const float* vgg, const float* pos_v_emb, const float* neg_v_emb,
+                  const float* lin_w, const float* lin_b, const float* fus_w, const float* fus_b, const float* labels,
+                  float loss_v_rate, int B, int V, int P, float* pred, float* loss, float* z, float* img_emb,
+                  float* pos_match, float* neg_match, float* posneg_emb, void* stream) {
+  UMPR_REQUIRE(B > 0 && V >= 0 && P >= 0, "head_fwd: bad shape");
+  UmprHead h;
+  memset(&h, 0, sizeof(h));
+  h.rr = rr; h.c_u = c_u; h.c_i = c_i; h.pp = prefer_pos; h.pn = prefer_neg; h.vgg = vgg; h.pos_v = pos_v_emb;
+  h.neg_v = neg_v_emb; h.lw = lin_w; h.lb = lin_b; h.fw = fus_w; h.fb = fus_b; h.labels = labels; h.rate = loss_v_rate;
+  h.B = B; h.V = V; h.P = P; h.F = 1000; h.pred = pred; h.loss = loss; h.z = z; h.img_emb = img_emb;
+  h.pos_match = pos_match; h.neg_match = neg_match; h.posneg_emb = posneg_emb;
+  return umpr_head_launch(h, 0, S(stream));
+}
+int umpr_head_bwd(const float* rr, const float* c_u, const float* c_i, const float* prefer_pos,
+                  const float* prefer_neg, const float* vgg, const float* pos_v_emb, const float* neg_v_emb,
+                  const float* lin_w, const float* fus_w, const float* labels, float loss_v_rate, int B, int V, int P,
+                  const float* pred, const float* z, const float* img_emb, const float* pos_match,
+                  const float* neg_match, const float* posneg_emb, const float* d_loss, const float* d_pred,
+                  float* d_rr, float* d_cu, float* d_ci, float* d_pp, float* d_pn, float* d_vgg, float* d_pos_v,
+                  float* d_neg_v, float* d_lin_w, float* d_lin_b, float* d_fus_w, float* d_fus_b, void* stream) {
+  UMPR_REQUIRE(((size_t)B + 3 * (size_t)B * V + 2 * V) * sizeof(float) <= 60000, "head_bwd: batch too large for one workgroup");
+  UmprHead h;
+  memset(&h, 0, sizeof(h));
+  h.rr = rr; h.c_u = c_u; h.c_i = c_i; h.pp = prefer_pos; h.pn = prefer_neg; h.vgg = vgg; h.pos_v = pos_v_emb;
+  h.neg_v = neg_v_emb; h.lw = lin_w; h.fw = fus_w; h.labels = labels; h.rate = loss_v_rate;
+  h.B = B; h.V = V; h.P = P; h.F = 1000;
+  h.pred = const_cast<float*>(pred); h.z = const_cast<float*>(z); h.img_emb = const_cast<float*>(img_emb);
+  h.pos_match = const_cast<float*>(pos_match); h.neg_match = const_cast<float*>(neg_match);
+  h.posneg_emb = const_cast<float*>(posneg_emb);
+  h.d_loss = d_loss; h.d_pred = d_pred; h.d_rr = d_rr; h.d_cu = d_cu; h.d_ci = d_ci; h.d_pp = d_pp; h.d_pn = d_pn;
+  h.d_vgg = d_vgg; h.d_pos_v = d_pos_v; h.d_neg_v = d_neg_v; h.d_lw = d_lin_w; h.d_lb = d_lin_b; h.d_fw = d_fus_w;
+  h.d_fb = d_fus_b;
+  return umpr_head_launch(h, 1, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+int umpr_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, long step, double grad_scale, void* stream) {
+  UMPR_REQUIRE(step >= 1 && n >= 0, "adam: bad step/n");
+  if (n == 0) return 0;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const double step_size = lr / bc1;
+  const double inv_bc2_sqrt = 1.0 / sqrt(bc2);
+  return umpr_adam_impl(p, g, m, v, n, (float)grad_scale, (float)weight_decay, (float)beta1, (float)beta2, (float)eps,
+                        (float)step_size, (float)inv_bc2_sqrt, S(stream));
+}
+
+}  // extern "C"

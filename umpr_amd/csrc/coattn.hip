@@ -1,0 +1,391 @@
+// R-Net co-attention (src/model.py:50-55) for gfx950, hidden width 2u = 128.
+//
+//   A = tanh(G_i M G_u^T)   soft_u = softmax_k(max_j A[j,k])   soft_i = softmax_j(max_k A[j,k])
+//   atte_u = G_u^T soft_u   atte_i = G_i^T soft_i                       (no padding mask, like the reference)
+//
+// The SLxSL affinity matrix is never written to HBM: T = G_i M comes from the GEMM kernel, `scores` forms 64x64
+// tiles of tanh(T G_u^T) on v_mfma_f32_32x32x2_f32 and keeps only row/column maxima with their (first) argmax, and
+// the backward is sparse (<= 2*SL non-zeros of dA per sample), routed through the saved argmax indices.
+#include "umpr_common.h"
+#include "umpr_internal.h"
+
+namespace {
+
+constexpr int D = 128;   // 2 * gru_size
+constexpr int LDT = 65;  // Ts[c][LDT], Us[c][LDT]
+
+struct ScoreParams {
+  const float* T;   // [B][SL][128] = G_i M
+  const float* Gu;  // [B][SL][128]
+  float* rowmax; int* argrow;        // [B][SL]
+  float* colmax_part; int* argcol_part;  // [B][nblk][SL]
+  int SL, nblk;
+};
+
+__device__ __forceinline__ void better_first(float& v, int& i, float v2, int i2) {
+  // keep the maximum; on ties the smaller index (first occurrence)
+  if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+
+__global__ __launch_bounds__(256) void coattn_scores_kernel(ScoreParams p) {
+  __shared__ float Ts[D * LDT];
+  __shared__ float Us[D * LDT];
+  __shared__ float xv[2][64]; __shared__ int xi[2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wu = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int SL = p.SL;
+  const int j0 = blk * 64;
+  const float* Tb = p.T + (long)b * SL * D;
+  const float* Ub = p.Gu + (long)b * SL * D;
+
+  for (int e = tid; e < 64 * D; e += 256) {
+    const int j = e / D, c = e % D;
+    Ts[c * LDT + j] = (j0 + j < SL) ? Tb[(long)(j0 + j) * D + c] : 0.f;
+  }
+  float rbest[16]; int ridx[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { rbest[r] = -INFINITY; ridx[r] = 0x7fffffff; }
+
+  const int ntile = (SL + 63) / 64;
+  for (int ut = 0; ut < ntile; ++ut) {
+    const int k0 = ut * 64;
+    __syncthreads();
+    for (int e = tid; e < 64 * D; e += 256) {
+      const int k = e / D, c = e % D;
+      Us[c * LDT + k] = (k0 + k < SL) ? Ub[(long)(k0 + k) * D + c] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < D / 2; ++kk) {
+      const int c = 2 * kk + kh;
+      acc = mfma32(Ts[c * LDT + wi * 32 + l31], Us[c * LDT + wu * 32 + l31], acc);
+    }
+    const int kcol = k0 + wu * 32 + l31;
+    const bool kvalid = kcol < SL;
+    float cbest = -INFINITY; int cidx = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + wi * 32 + mfma_row(r, lane);
+      const float a = tanhf(acc[r]);
+      if (kvalid && j < SL) {
+        better_first(rbest[r], ridx[r], a, kcol);
+        better_first(cbest, cidx, a, j);
+      }
+    }
+    // column max: combine the two lane halves (rows +4), then the two wi waves
+    {
+      const float ov = __shfl_xor(cbest, 32, 64);
+      const int oi = __shfl_xor(cidx, 32, 64);
+      better_first(cbest, cidx, ov, oi);
+    }
+    if (wi == 1 && kh == 0) { xv[wu][l31] = cbest; xi[wu][l31] = cidx; }
+    __syncthreads();
+    if (wi == 0 && kh == 0) {
+      better_first(cbest, cidx, xv[wu][l31], xi[wu][l31]);
+      if (kvalid) {
+        const long o = ((long)b * p.nblk + blk) * SL + kcol;
+        p.colmax_part[o] = cbest;
+        p.argcol_part[o] = cidx;
+      }
+    }
+  }
+  // row max: reduce over the 32 lanes of each half (columns), then over the two wu waves
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = rbest[r]; int i = ridx[r];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(i, o, 64);
+      better_first(v, i, ov, oi);
+    }
+    rbest[r] = v; ridx[r] = i;
+  }
+  // rows of this wave: wi*32 + mfma_row(r, lane); lanes l31==0 of each half hold the result
+  if (wu == 1 && l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jr = wi * 32 + mfma_row(r, lane);
+      xv[0][jr] = rbest[r]; xi[0][jr] = ridx[r];
+    }
+  }
+  __syncthreads();
+  if (wu == 0 && l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jr = wi * 32 + mfma_row(r, lane);
+      float v = rbest[r]; int i = ridx[r];
+      better_first(v, i, xv[0][jr], xi[0][jr]);
+      if (j0 + jr < SL) {
+        p.rowmax[(long)b * SL + j0 + jr] = v;
+        p.argrow[(long)b * SL + j0 + jr] = i;
+      }
+    }
+  }
+}
+
+__device__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+__device__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s = fmaxf(s, red[w]);
+  return s;
+}
+
+struct FinishParams {
+  const float* Gu; const float* Gi;
+  const float* colmax_part; const int* argcol_part; int nblk;
+  const float* rowmax;
+  float* colmax; int* argcol;
+  float* soft_u; float* soft_i;
+  float* atte_u; long ld_u;  // atte_u[b*ld_u + c]
+  float* atte_i; long ld_i;
+  int SL;
+};
+
+__global__ __launch_bounds__(256) void coattn_finish_kernel(FinishParams p) {
+  extern __shared__ float sm[];  // su[SL], si[SL]
+  __shared__ float red[4];
+  __shared__ float part[2][D];
+  const int tid = threadIdx.x, b = blockIdx.x, SL = p.SL;
+  float* su = sm; float* si = sm + SL;
+  float mu = -INFINITY, mi = -INFINITY;
+  for (int k = tid; k < SL; k += 256) {
+    float v = -INFINITY; int idx = 0x7fffffff;
+    for (int q = 0; q < p.nblk; ++q) {
+      const long o = ((long)b * p.nblk + q) * SL + k;
+      better_first(v, idx, p.colmax_part[o], p.argcol_part[o]);
+    }
+    p.colmax[(long)b * SL + k] = v; p.argcol[(long)b * SL + k] = idx;
+    su[k] = v; mu = fmaxf(mu, v);
+    const float rv = p.rowmax[(long)b * SL + k];
+    si[k] = rv; mi = fmaxf(mi, rv);
+  }
+  mu = block_max(mu, red);
+  mi = block_max(mi, red);
+  float zu = 0.f, zi = 0.f;
+  for (int k = tid; k < SL; k += 256) {
+    const float eu = expf(su[k] - mu), ei = expf(si[k] - mi);
+    su[k] = eu; si[k] = ei; zu += eu; zi += ei;
+  }
+  zu = block_sum(zu, red);
+  zi = block_sum(zi, red);
+  for (int k = tid; k < SL; k += 256) {
+    su[k] /= zu; si[k] /= zi;
+    p.soft_u[(long)b * SL + k] = su[k];
+    p.soft_i[(long)b * SL + k] = si[k];
+  }
+  __syncthreads();
+  const int c = tid & 127, half = tid >> 7;
+  for (int which = 0; which < 2; ++which) {
+    const float* G = (which == 0 ? p.Gu : p.Gi) + (long)b * SL * D;
+    const float* s = which == 0 ? su : si;
+    float a = 0.f;
+    for (int k = half; k < SL; k += 2) a += s[k] * G[(long)k * D + c];
+    part[half][c] = a;
+    __syncthreads();
+    if (half == 0) {
+      const float v = part[0][c] + part[1][c];
+      if (which == 0) p.atte_u[(long)b * p.ld_u + c] = v; else p.atte_i[(long)b * p.ld_i + c] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct BwdPrepParams {
+  const float* Gu; const float* Gi;
+  const float* d_atte_u; long ld_du; const float* d_atte_i; long ld_di;   // [B][128] (strided rows)
+  const float* d_soft_u; const float* d_soft_i;                           // [B][SL] or null
+  const float* soft_u; const float* soft_i; const float* colmax; const float* rowmax;
+  float* dSc; float* dSr;  // [B][SL]
+  int SL;
+};
+
+__global__ __launch_bounds__(256) void coattn_bwd_prep_kernel(BwdPrepParams p) {
+  extern __shared__ float sm[];  // ds_u[SL], ds_i[SL]
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, SL = p.SL;
+  float* dsu = sm; float* dsi = sm + SL;
+  const float dau0 = p.d_atte_u[(long)b * p.ld_du + lane], dau1 = p.d_atte_u[(long)b * p.ld_du + 64 + lane];
+  const float dai0 = p.d_atte_i[(long)b * p.ld_di + lane], dai1 = p.d_atte_i[(long)b * p.ld_di + 64 + lane];
+  for (int k = wave; k < SL; k += 4) {
+    const float* gu = p.Gu + ((long)b * SL + k) * D;
+    const float* gi = p.Gi + ((long)b * SL + k) * D;
+    float su = gu[lane] * dau0 + gu[64 + lane] * dau1;
+    float si = gi[lane] * dai0 + gi[64 + lane] * dai1;
+    su = wave_sum(su); si = wave_sum(si);
+    if (lane == 0) {
+      dsu[k] = su + (p.d_soft_u ? p.d_soft_u[(long)b * SL + k] : 0.f);
+      dsi[k] = si + (p.d_soft_i ? p.d_soft_i[(long)b * SL + k] : 0.f);
+    }
+  }
+  __syncthreads();
+  float du = 0.f, di = 0.f;
+  for (int k = tid; k < SL; k += 256) {
+    du += p.soft_u[(long)b * SL + k] * dsu[k];
+    di += p.soft_i[(long)b * SL + k] * dsi[k];
+  }
+  du = block_sum(du, red);
+  di = block_sum(di, red);
+  for (int k = tid; k < SL; k += 256) {
+    const long o = (long)b * SL + k;
+    const float cm = p.colmax[o], rm = p.rowmax[o];
+    p.dSc[o] = p.soft_u[o] * (dsu[k] - du) * (1.f - cm * cm);
+    p.dSr[o] = p.soft_i[o] * (dsi[k] - di) * (1.f - rm * rm);
+  }
+}
+
+struct BwdRowsParams {
+  const float* Gu; const float* T;
+  const float* soft_u; const float* soft_i;
+  const float* d_atte_u; long ld_du; const float* d_atte_i; long ld_di;
+  const float* dSc; const float* dSr; const int* argcol; const int* argrow;
+  float* dGu;  // [B][SL][128]  = soft_u d_atte_u + routed dS T
+  float* dT;   // [B][SL][128]
+  float* dGi;  // [B][SL][128]  initialised with soft_i d_atte_i (the GEMM dT M^T accumulates onto it)
+  int SL; int accumulate;  // accumulate: add onto the caller's dGu / dGi instead of overwriting
+};
+
+__global__ __launch_bounds__(256) void coattn_bwd_rows_kernel(BwdRowsParams p) {
+  extern __shared__ float sm[];  // dSc[SL], dSr[SL], argcol[SL], argrow[SL]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, SL = p.SL;
+  float* sc = sm; float* sr = sm + SL;
+  int* ac = reinterpret_cast<int*>(sm + 2 * SL); int* ar = ac + SL;
+  for (int k = tid; k < SL; k += 256) {
+    const long o = (long)b * SL + k;
+    sc[k] = p.dSc[o]; sr[k] = p.dSr[o]; ac[k] = p.argcol[o]; ar[k] = p.argrow[o];
+  }
+  __syncthreads();
+  const float* Gu = p.Gu + (long)b * SL * D;
+  const float* T = p.T + (long)b * SL * D;
+  const float dau0 = p.d_atte_u[(long)b * p.ld_du + lane], dau1 = p.d_atte_u[(long)b * p.ld_du + 64 + lane];
+  const float dai0 = p.d_atte_i[(long)b * p.ld_di + lane], dai1 = p.d_atte_i[(long)b * p.ld_di + 64 + lane];
+  const int rows_per_block = 16;
+  const int r0 = blockIdx.x * rows_per_block;
+  for (int rr = wave; rr < rows_per_block; rr += 4) {
+    const int row = r0 + rr;
+    if (row >= SL) break;
+    const long o = ((long)b * SL + row) * D;
+    // ---- dG_u[row] (row is a u position k)
+    {
+      const float su = p.soft_u[(long)b * SL + row];
+      const int j = ac[row];
+      const float w = sc[row];
+      float a0 = su * dau0 + w * T[(long)j * D + lane];
+      float a1 = su * dau1 + w * T[(long)j * D + 64 + lane];
+      for (int base = 0; base < SL; base += 64) {
+        const int jj = base + lane;
+        unsigned long long m = __ballot(jj < SL && ar[jj] == row);
+        while (m) {
+          const int q = base + __builtin_ctzll(m);
+          m &= m - 1;
+          const float wq = sr[q];
+          a0 += wq * T[(long)q * D + lane];
+          a1 += wq * T[(long)q * D + 64 + lane];
+        }
+      }
+      if (p.accumulate) { a0 += p.dGu[o + lane]; a1 += p.dGu[o + 64 + lane]; }
+      p.dGu[o + lane] = a0; p.dGu[o + 64 + lane] = a1;
+    }
+    // ---- dT[row] (row is an i position j)
+    {
+      const int k = ar[row];
+      const float w = sr[row];
+      float a0 = w * Gu[(long)k * D + lane];
+      float a1 = w * Gu[(long)k * D + 64 + lane];
+      for (int base = 0; base < SL; base += 64) {
+        const int kk = base + lane;
+        unsigned long long m = __ballot(kk < SL && ac[kk] == row);
+        while (m) {
+          const int q = base + __builtin_ctzll(m);
+          m &= m - 1;
+          const float wq = sc[q];
+          a0 += wq * Gu[(long)q * D + lane];
+          a1 += wq * Gu[(long)q * D + 64 + lane];
+        }
+      }
+      p.dT[o + lane] = a0; p.dT[o + 64 + lane] = a1;
+      const float si = p.soft_i[(long)b * SL + row];
+      float g0 = si * dai0, g1 = si * dai1;
+      if (p.accumulate) { g0 += p.dGi[o + lane]; g1 += p.dGi[o + 64 + lane]; }
+      p.dGi[o + lane] = g0; p.dGi[o + 64 + lane] = g1;
+    }
+  }
+}
+
+}  // namespace
+
+// workspace floats needed by forward: T [B*SL*128] + colmax_part [B*nblk*SL] + argcol_part (int) [B*nblk*SL]
+size_t umpr_coattn_fwd_ws_bytes(int B, int SL) {
+  const int nblk = cdiv(SL, 64);
+  return ((size_t)B * nblk * SL * 2) * sizeof(float);
+}
+
+int umpr_coattn_fwd_impl(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
+                         float* soft_i, float* atte_u, long ld_u, float* atte_i, long ld_i, float* colmax, int* argcol,
+                         float* rowmax, int* argrow, float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(B > 0 && SL > 0, "coattn: bad shape");
+  UMPR_REQUIRE(ws_bytes >= umpr_coattn_fwd_ws_bytes(B, SL), "coattn: workspace too small");
+  const int nblk = cdiv(SL, 64);
+  UmprGemm g;
+  g.A = Gi; g.lda = D; g.B = M; g.ldb = D; g.C = T; g.ldc = D; g.M = B * SL; g.N = D; g.K = D;
+  if (int rc = umpr_gemm(g, s)) return rc;
+  float* cpart = ws;
+  int* apart = reinterpret_cast<int*>(ws + (size_t)B * nblk * SL);
+  ScoreParams sp{T, Gu, rowmax, argrow, cpart, apart, SL, nblk};
+  coattn_scores_kernel<<<dim3(nblk, B), 256, 0, s>>>(sp);
+  UMPR_LAUNCH_CHECK("coattn_scores");
+  FinishParams fp{Gu, Gi, cpart, apart, nblk, rowmax, colmax, argcol, soft_u, soft_i, atte_u, ld_u, atte_i, ld_i, SL};
+  coattn_finish_kernel<<<B, 256, 2 * SL * sizeof(float), s>>>(fp);
+  UMPR_LAUNCH_CHECK("coattn_finish");
+  return 0;
+}
+
+// backward: needs dSc,dSr [B*SL] each + dT [B*SL*128] in ws; split-K slab for dM after that
+size_t umpr_coattn_bwd_ws_bytes(int B, int SL) {
+  return ((size_t)B * SL * 2 + (size_t)B * SL * D + (size_t)512 * D * D) * sizeof(float);
+}
+
+int umpr_coattn_bwd_impl(const float* Gu, const float* Gi, const float* M, const float* T, const float* soft_u,
+                         const float* soft_i, const float* colmax, const int* argcol, const float* rowmax,
+                         const int* argrow, const float* d_atte_u, long ld_du, const float* d_atte_i, long ld_di,
+                         const float* d_soft_u, const float* d_soft_i, int B, int SL, float* dGu, float* dGi, float* dM,
+                         int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(ws_bytes >= umpr_coattn_bwd_ws_bytes(B, SL), "coattn_bwd: workspace too small");
+  float* dSc = ws; float* dSr = ws + (size_t)B * SL; float* dT = dSr + (size_t)B * SL;
+  float* slab = dT + (size_t)B * SL * D;
+  BwdPrepParams pp{Gu, Gi, d_atte_u, ld_du, d_atte_i, ld_di, d_soft_u, d_soft_i, soft_u, soft_i, colmax, rowmax, dSc, dSr, SL};
+  coattn_bwd_prep_kernel<<<B, 256, 2 * SL * sizeof(float), s>>>(pp);
+  UMPR_LAUNCH_CHECK("coattn_bwd_prep");
+  BwdRowsParams rp{Gu, T, soft_u, soft_i, d_atte_u, ld_du, d_atte_i, ld_di, dSc, dSr, argcol, argrow, dGu, dT, dGi, SL, accumulate};
+  coattn_bwd_rows_kernel<<<dim3(cdiv(SL, 16), B), 256, 4 * SL * sizeof(float), s>>>(rp);
+  UMPR_LAUNCH_CHECK("coattn_bwd_rows");
+  // dG_i += dT M^T
+  UmprGemm g;
+  g.A = dT; g.lda = D; g.B = M; g.ldb = D; g.transB = true; g.C = dGi; g.ldc = D; g.M = B * SL; g.N = D; g.K = D;
+  g.accumulate = true;
+  if (int rc = umpr_gemm(g, s)) return rc;
+  // dM = G_i^T dT   (K = B*SL, split-K)
+  UmprGemm h;
+  h.A = Gi; h.lda = D; h.transA = true; h.B = dT; h.ldb = D; h.C = dM; h.ldc = D; h.M = D; h.N = D; h.K = B * SL;
+  h.split_k = 0; h.ws = slab; h.ws_bytes = (size_t)512 * D * D * sizeof(float);
+  return umpr_gemm(h, s);
+}

@@ -1,0 +1,200 @@
+// Generic fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain) for gfx950.
+//
+//   C[M][N] = act( alpha * sum_k A(m,k) * B(k,n) + bias + (accumulate ? C : 0) )
+//
+// A(m,k) = transA ? A[k*lda+m] : A[gatherA(m)*lda+k]      B(k,n) = transB ? B[n*ldb+k] : B[gatherB(k)*ldb+n]
+// Used for every GEMM-shaped piece of the UMPR path that is not the 3x3 convolution: GRU input projection
+// (fused embedding-row gather), co-attention projections, SNet / CNet projections, VGG classifier, and all
+// the weight-gradient contractions (split-K, deterministic slab reduce).
+//
+// Tiling: 256 threads = 4 waves (2x2); block tile BMxBNx16, LDS images are k-major ([k][m], [k][n]) so an MFMA
+// operand read is 32 consecutive floats per half-wave (conflict-free ds_read_b32); global->register prefetch
+// of tile t+1 is issued before the MFMAs of tile t, written to the other LDS buffer afterwards (one barrier
+// per k-tile).  MFMA-A = rows of C (m), MFMA-B = columns of C (n): lanes run along n, so C stores are 128-B
+// row segments.
+#include "umpr_common.h"
+#include "umpr_internal.h"
+#include "umpr_tiles.h"
+
+namespace {
+
+struct GemmParams {
+  const float* A; long lda;
+  const float* B; long ldb;
+  float* C; long ldc;
+  int M, N, K;
+  const int64_t* gatherA;
+  const int64_t* gatherB;
+  const float* bias; int bias_mode;  // 1: bias[n], 2: bias[m]
+  int act; int accumulate; float alpha;
+  int split_k; int k_per_split; float* ws;
+  int vecA, vecB;
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+  using LA = TileRegs<BM, !TA>;  // A non-trans is k-contiguous
+  using LB = TileRegs<BN, TB>;   // B trans is k-contiguous
+  constexpr int LDA = LA::LD, LDB = LB::LD;
+  constexpr int WTM = BM / 2, WTN = BN / 2;  // 2x2 waves
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int split = blockIdx.z;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  LA ra;
+  LB rb;
+  const int nt = (kend - kbeg + BK - 1) / BK;
+  if (nt > 0) {
+    ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg, kend, p.vecA, tid);
+    rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg, kend, p.vecB, tid);
+    ra.store(As[0], tid);
+    rb.store(Bs[0], tid);
+  }
+  __syncthreads();
+  const int l31 = lane & 31, kh = lane >> 5;
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg + (t + 1) * BK, kend, p.vecA, tid);
+      rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg + (t + 1) * BK, kend, p.vecB, tid);
+    }
+    const float* as = As[cur] + wm * WTM + l31;
+    const float* bs = Bs[cur] + wn * WTN + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + kh) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + kh) * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+    if (t + 1 < nt) {
+      ra.store(As[cur ^ 1], tid);
+      rb.store(Bs[cur ^ 1], tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + mfma_row(r, lane);
+        if (row < p.M && col < p.N) {
+          float v = p.alpha * acc[i][j][r];
+          if (p.split_k > 1) {
+            p.ws[((long)split * p.M + row) * p.N + col] = v;
+          } else {
+            if (p.bias_mode == 1) v += p.bias[col];
+            else if (p.bias_mode == 2) v += p.bias[row];
+            float* c = p.C + (long)row * p.ldc + col;
+            if (p.accumulate) v += *c;
+            *c = apply_act(v, p.act);
+          }
+        }
+      }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* __restrict__ C,
+                                     long ldc, const float* __restrict__ bias, int bias_mode, int act, int accumulate) {
+  const long total = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / N), col = (int)(i % N);
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += ws[(long)s * total + i];  // fixed order: bitwise reproducible
+    if (bias_mode == 1) v += bias[col];
+    else if (bias_mode == 2) v += bias[row];
+    float* c = C + (long)row * ldc + col;
+    if (accumulate) v += *c;
+    *c = apply_act(v, act);
+  }
+}
+
+template <int BM, int BN>
+void launch_tile(const GemmParams& p, bool ta, bool tb, dim3 grid, hipStream_t s) {
+  if (!ta && !tb) gemm_f32_kernel<BM, BN, false, false><<<grid, 256, 0, s>>>(p);
+  else if (!ta && tb) gemm_f32_kernel<BM, BN, false, true><<<grid, 256, 0, s>>>(p);
+  else if (ta && !tb) gemm_f32_kernel<BM, BN, true, false><<<grid, 256, 0, s>>>(p);
+  else gemm_f32_kernel<BM, BN, true, true><<<grid, 256, 0, s>>>(p);
+}
+
+}  // namespace
+
+int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
+  UMPR_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
+  UMPR_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
+  UMPR_REQUIRE(!(g.gatherA && g.transA) || true, "gemm");
+  GemmParams p;
+  p.A = g.A; p.lda = g.lda; p.B = g.B; p.ldb = g.ldb; p.C = g.C; p.ldc = g.ldc;
+  p.M = g.M; p.N = g.N; p.K = g.K;
+  p.gatherA = g.gatherA; p.gatherB = g.gatherB;
+  p.bias = g.bias; p.bias_mode = g.bias ? g.bias_mode : 0;
+  p.act = g.act; p.accumulate = g.accumulate ? 1 : 0; p.alpha = g.alpha;
+  p.vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  p.vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+  const int BM = g.M <= 64 ? 64 : 128;
+  const int BN = g.N <= 64 ? 64 : 128;
+  const int tm = cdiv(g.M, BM), tn = cdiv(g.N, BN);
+  int split = g.split_k;
+  if (split <= 0) {  // auto: aim for >= 512 workgroups when K is deep enough to share
+    split = 1;
+    const long tiles = (long)tm * tn;
+    if (tiles < 256 && g.K >= 512) {
+      split = (int)((512 + tiles - 1) / tiles);
+      const int maxs = g.K / 128;
+      if (split > maxs) split = maxs;
+      if (split < 1) split = 1;
+    }
+  }
+  if (split > 1) {
+    const size_t need = (size_t)split * g.M * g.N * sizeof(float);
+    if (!g.ws || g.ws_bytes < need) {
+      const size_t per = (size_t)g.M * g.N * sizeof(float);
+      split = g.ws ? (int)(g.ws_bytes / per) : 1;
+      if (split < 1) split = 1;
+    }
+  }
+  int kps = cdiv(cdiv(g.K, split), BK) * BK;
+  if (kps < BK) kps = BK;
+  split = g.K > 0 ? cdiv(g.K, kps) : 1;
+  p.split_k = split; p.k_per_split = kps; p.ws = g.ws;
+  dim3 grid(tn, tm, split);
+  if (BM == 128 && BN == 128) launch_tile<128, 128>(p, g.transA, g.transB, grid, stream);
+  else if (BM == 64 && BN == 128) launch_tile<64, 128>(p, g.transA, g.transB, grid, stream);
+  else if (BM == 128 && BN == 64) launch_tile<128, 64>(p, g.transA, g.transB, grid, stream);
+  else launch_tile<64, 64>(p, g.transA, g.transB, grid, stream);
+  UMPR_LAUNCH_CHECK("gemm_f32");
+  if (split > 1) {
+    const long total = (long)g.M * g.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    splitk_reduce_kernel<<<blocks, 256, 0, stream>>>(g.ws, split, g.M, g.N, g.C, g.ldc, p.bias, p.bias_mode, g.act,
+                                                     p.accumulate);
+    UMPR_LAUNCH_CHECK("splitk_reduce");
+  }
+  return 0;
+}

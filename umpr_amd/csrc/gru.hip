@@ -1,0 +1,319 @@
+// Bidirectional variable-length GRU (hidden 64) for gfx950: recurrent forward and BPTT.
+//
+// Reference semantics: ImprovedRnn.forward, src/model.py:12-21 = pack_padded_sequence -> nn.GRU -> pad_packed_sequence
+// (zeros past each length) -> an extra gather by unsorted_indices.  Here the host passes the permutation
+// (dst_row[n] = sorted_indices[n]: input row n is written to output row dst_row[n]) and lengths as int32 device
+// arrays; `order` groups sequences of similar length into one workgroup (64 sequences x one direction).
+//
+// Per step the workgroup computes gh[seq][gate] = H[seq][64] * W_hh^T[64][192] on v_mfma_f32_32x32x2_f32 with the
+// hidden state and W_hh staged in LDS; D lanes run along the hidden unit, so the gx loads, the out/saved stores and
+// the dgx stores are 128-B coalesced segments.  Gate order (r,z,n); n = tanh(gx_n + r*(W_hn h + b_hn)).
+#include "umpr_common.h"
+#include "umpr_internal.h"
+
+namespace {
+
+constexpr int H = 64;      // hidden size (config.gru_size)
+constexpr int G3 = 192;    // 3*H
+constexpr int TS = 64;     // sequences per workgroup
+constexpr int LDH = 65;    // Hs[k][LDH]
+
+struct GruFwdParams {
+  const float* gx;       // [N][L][384] = W_ih x + b_ih for (fwd | reverse)
+  const float* whh[2];   // [192][64]
+  const float* bhh[2];   // [192]
+  const int* lengths;    // [N]
+  const int* order;      // [N]
+  const int* dst_row;    // [N]
+  float* out;            // [N][L][128], pre-zeroed
+  float* saved;          // [2][N][L][4][64] (r, z, n, W_hn h + b_hn) or null
+  int N, L;
+};
+
+__global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdParams p) {
+  __shared__ float Ws[H * G3];        // Ws[k][gate col] = W_hh[gate col][k]
+  __shared__ float Hs[H * LDH];       // Hs[k][seq]
+  __shared__ int s_n[TS], s_len[TS], s_dst[TS];
+  __shared__ int s_maxlen;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws = wave >> 1, wh = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int dir = blockIdx.y;
+  const int tile = blockIdx.x;
+
+  if (tid == 0) s_maxlen = 0;
+  __syncthreads();
+  if (tid < TS) {
+    const int pos = tile * TS + tid;
+    int n = -1, len = 0, dst = 0;
+    if (pos < p.N) {
+      n = p.order[pos];
+      len = p.lengths[n];
+      if (len > p.L) len = p.L;
+      dst = p.dst_row[n];
+    }
+    s_n[tid] = n; s_len[tid] = len; s_dst[tid] = dst;
+    atomicMax(&s_maxlen, len);
+  }
+  const float* whh = p.whh[dir];
+  for (int e = tid; e < G3 * H; e += 256) {
+    const int j = e / H, k = e % H;  // global is [j][k], k contiguous
+    Ws[k * G3 + j] = whh[e];
+  }
+  for (int e = tid; e < H * LDH; e += 256) Hs[e] = 0.f;
+  __syncthreads();
+  const int maxlen = s_maxlen;
+  const int hid = wh * 32 + l31;
+  float bh[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) bh[g] = p.bhh[dir][g * H + hid];
+  float hreg[16];
+  int nreg[16], lreg[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    hreg[r] = 0.f;
+    const int seq = ws * 32 + mfma_row(r, lane);
+    nreg[r] = s_n[seq];
+    lreg[r] = s_len[seq];
+  }
+
+  for (int step = 0; step < maxlen; ++step) {
+    const int t = dir == 0 ? step : maxlen - 1 - step;
+    float gxr[3][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool act = t < lreg[r];
+      const float* g = p.gx + ((long)nreg[r] * p.L + t) * 384 + dir * G3 + hid;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) gxr[q][r] = act ? g[q * H] : 0.f;
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = bh[q];
+#pragma unroll 8
+    for (int kk = 0; kk < H / 2; ++kk) {
+      const int k = 2 * kk + kh;
+      const float a = Hs[k * LDH + ws * 32 + l31];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = mfma32(a, Ws[k * G3 + q * H + hid], acc[q]);
+    }
+    __syncthreads();  // every wave has finished reading Hs for this step
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool act = t < lreg[r];
+      if (act) {
+        const float rr = sigmoidf_(gxr[0][r] + acc[0][r]);
+        const float zz = sigmoidf_(gxr[1][r] + acc[1][r]);
+        const float hn = acc[2][r];
+        const float nn = tanhf(gxr[2][r] + rr * hn);
+        const float hnew = (1.f - zz) * nn + zz * hreg[r];
+        hreg[r] = hnew;
+        const int seq = ws * 32 + mfma_row(r, lane);
+        p.out[((long)s_dst[seq] * p.L + t) * 128 + dir * H + hid] = hnew;
+        if (p.saved) {
+          float* sv = p.saved + ((((long)dir * p.N + nreg[r]) * p.L + t) * 4) * H + hid;
+          sv[0] = rr; sv[H] = zz; sv[2 * H] = nn; sv[3 * H] = hn;
+        }
+        Hs[hid * LDH + seq] = hnew;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct GruBwdParams {
+  const float* dout;     // [N][L][128] gradient of the (permuted) output
+  const float* out;      // [N][L][128] forward output (source of h_{t-1})
+  const float* saved;    // [2][N][L][4][64]
+  const float* whh[2];
+  const int* lengths;
+  const int* order;
+  const int* dst_row;
+  float* dgx;            // [N][L][384], pre-zeroed
+  float* dwhh_slab;      // [tiles][2][192][64]
+  float* dbias_slab;     // [tiles][2][2][192]  (db_ih, db_hh)
+  int N, L;
+};
+
+constexpr int LDG = 65;  // DG[gate][LDG]
+
+__global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
+  __shared__ float Ws[G3 * H];     // Ws[gate][hid] = W_hh (natural layout)
+  __shared__ float DG[G3 * LDG];   // DG[gate][seq]
+  __shared__ float HP[TS * H];     // HP[seq][hid] = h_{prev}
+  __shared__ float sb[2 * G3];
+  __shared__ int s_n[TS], s_len[TS], s_dst[TS];
+  __shared__ int s_maxlen;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws = wave >> 1, wh = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int dir = blockIdx.y, tile = blockIdx.x;
+
+  if (tid == 0) s_maxlen = 0;
+  __syncthreads();
+  if (tid < TS) {
+    const int pos = tile * TS + tid;
+    int n = -1, len = 0, dst = 0;
+    if (pos < p.N) {
+      n = p.order[pos];
+      len = p.lengths[n];
+      if (len > p.L) len = p.L;
+      dst = p.dst_row[n];
+    }
+    s_n[tid] = n; s_len[tid] = len; s_dst[tid] = dst;
+    atomicMax(&s_maxlen, len);
+  }
+  for (int e = tid; e < G3 * H; e += 256) Ws[e] = p.whh[dir][e];
+  for (int e = tid; e < 2 * G3; e += 256) sb[e] = 0.f;
+  __syncthreads();
+  const int maxlen = s_maxlen;
+  const int hid = wh * 32 + l31;
+  float dh[16];
+  int nreg[16], lreg[16], dreg[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    dh[r] = 0.f;
+    const int seq = ws * 32 + mfma_row(r, lane);
+    nreg[r] = s_n[seq]; lreg[r] = s_len[seq]; dreg[r] = s_dst[seq];
+  }
+  f32x16 accw[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
+  float sbi[3] = {0.f, 0.f, 0.f}, sbh[3] = {0.f, 0.f, 0.f};
+
+  for (int step = 0; step < maxlen; ++step) {
+    // reverse of the forward order
+    const int t = dir == 0 ? maxlen - 1 - step : step;
+    const int tp = dir == 0 ? t - 1 : t + 1;
+    float dcarry[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int seq = ws * 32 + mfma_row(r, lane);
+      const bool act = t < lreg[r];
+      float drp = 0.f, dzp = 0.f, dghn = 0.f, hp = 0.f;
+      dcarry[r] = dh[r];
+      if (act) {
+        const long orow = ((long)dreg[r] * p.L) * 128 + dir * H + hid;
+        const float dtot = dh[r] + p.dout[orow + (long)t * 128];
+        if (tp >= 0 && tp < lreg[r]) hp = p.out[orow + (long)tp * 128];
+        const float* sv = p.saved + ((((long)dir * p.N + nreg[r]) * p.L + t) * 4) * H + hid;
+        const float rr = sv[0], zz = sv[H], nn = sv[2 * H], hn = sv[3 * H];
+        const float dnp = dtot * (1.f - zz) * (1.f - nn * nn);
+        dzp = dtot * (hp - nn) * zz * (1.f - zz);
+        drp = dnp * hn * rr * (1.f - rr);
+        dghn = dnp * rr;
+        float* g = p.dgx + ((long)nreg[r] * p.L + t) * 384 + dir * G3 + hid;
+        g[0] = drp; g[H] = dzp; g[2 * H] = dnp;
+        dcarry[r] = dtot * zz;
+        sbi[0] += drp; sbi[1] += dzp; sbi[2] += dnp;
+        sbh[0] += drp; sbh[1] += dzp; sbh[2] += dghn;
+      }
+      DG[(hid)*LDG + seq] = drp;
+      DG[(H + hid) * LDG + seq] = dzp;
+      DG[(2 * H + hid) * LDG + seq] = dghn;
+      HP[seq * H + hid] = hp;
+    }
+    __syncthreads();
+    // dh_prev[seq][hid] += sum_gate dgh[seq][gate] * W_hh[gate][hid]
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < G3 / 2; ++kk) {
+      const int k = 2 * kk + kh;
+      acc = mfma32(DG[k * LDG + ws * 32 + l31], Ws[k * H + hid], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[r] = dcarry[r] + acc[r];  // inactive rows: dgh = 0 -> acc = 0, carry = dh
+    // dW_hh[gate][hid] += sum_seq dgh[seq][gate] * h_prev[seq][hid]
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = wave * 3 + i;
+      const int gt = idx >> 1, ht = idx & 1;
+#pragma unroll 8
+      for (int kk = 0; kk < TS / 2; ++kk) {
+        const int k = 2 * kk + kh;
+        accw[i] = mfma32(DG[(gt * 32 + l31) * LDG + k], HP[k * H + ht * 32 + l31], accw[i]);
+      }
+    }
+    __syncthreads();
+  }
+
+  float* slab = p.dwhh_slab + ((long)tile * 2 + dir) * G3 * H;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = wave * 3 + i;
+    const int gt = idx >> 1, ht = idx & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[(gt * 32 + mfma_row(r, lane)) * H + ht * 32 + l31] = accw[i][r];
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    atomicAdd(&sb[q * H + hid], sbi[q]);
+    atomicAdd(&sb[G3 + q * H + hid], sbh[q]);
+  }
+  __syncthreads();
+  float* bs = p.dbias_slab + ((long)tile * 2 + dir) * 2 * G3;
+  for (int e = tid; e < 2 * G3; e += 256) bs[e] = sb[e];
+}
+
+// dst[j] (+)= sum_i src[i][j]   (rows x cols, fixed order)
+__global__ void colsum_rows_kernel(const float* __restrict__ src, int rows, long cols, long row_stride,
+                                   float* __restrict__ dst, int accumulate) {
+  for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < cols; j += (long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int i = 0; i < rows; ++i) v += src[(long)i * row_stride + j];
+    dst[j] = accumulate ? dst[j] + v : v;
+  }
+}
+
+}  // namespace
+
+int umpr_colsum_rows(const float* src, int rows, long cols, long row_stride, float* dst, int accumulate, hipStream_t s) {
+  int blocks = (int)((cols + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  colsum_rows_kernel<<<blocks, 256, 0, s>>>(src, rows, cols, row_stride, dst, accumulate);
+  UMPR_LAUNCH_CHECK("colsum_rows");
+  return 0;
+}
+
+int umpr_gru_recurrent_fwd(const float* gx, const float* whh_f, const float* bhh_f, const float* whh_r,
+                           const float* bhh_r, const int* lengths, const int* order, const int* dst_row, float* out,
+                           float* saved, int N, int L, hipStream_t s) {
+  GruFwdParams p;
+  p.gx = gx; p.whh[0] = whh_f; p.whh[1] = whh_r; p.bhh[0] = bhh_f; p.bhh[1] = bhh_r;
+  p.lengths = lengths; p.order = order; p.dst_row = dst_row; p.out = out; p.saved = saved; p.N = N; p.L = L;
+  if (hipMemsetAsync(out, 0, (size_t)N * L * 128 * sizeof(float), s) != hipSuccess) {
+    umpr_set_error("gru_fwd: memset failed");
+    return -2;
+  }
+  dim3 grid(cdiv(N, TS), 2);
+  gru_fwd_kernel<<<grid, 256, 0, s>>>(p);
+  UMPR_LAUNCH_CHECK("gru_fwd");
+  return 0;
+}
+
+int umpr_gru_tiles(int N) { return cdiv(N, TS); }
+
+int umpr_gru_bptt(const float* dout, const float* out, const float* saved, const float* whh_f, const float* whh_r,
+                  const int* lengths, const int* order, const int* dst_row, float* dgx, float* dwhh_slab,
+                  float* dbias_slab, int N, int L, hipStream_t s) {
+  GruBwdParams p;
+  p.dout = dout; p.out = out; p.saved = saved; p.whh[0] = whh_f; p.whh[1] = whh_r;
+  p.lengths = lengths; p.order = order; p.dst_row = dst_row; p.dgx = dgx; p.dwhh_slab = dwhh_slab;
+  p.dbias_slab = dbias_slab; p.N = N; p.L = L;
+  if (hipMemsetAsync(dgx, 0, (size_t)N * L * 384 * sizeof(float), s) != hipSuccess) {
+    umpr_set_error("gru_bwd: memset failed");
+    return -2;
+  }
+  dim3 grid(cdiv(N, TS), 2);
+  gru_bwd_kernel<<<grid, 256, 0, s>>>(p);
+  UMPR_LAUNCH_CHECK("gru_bwd");
+  return 0;
+}

@@ -1,0 +1,796 @@
+// Small fused text-path kernels of UMPR for gfx950 (all HBM/latency bound, one wave per sentence or one
+// workgroup per sample; reductions by wavefront shuffles, fixed summation order = bitwise reproducible):
+//   S-Net pooling (src/model.py:75-80), C-Net head (src/model.py:118-125), control gate incl. SS-Net
+//   (src/model.py:186-197,142-143), visual head + fusion + losses (src/model.py:218-228,268-277).
+#include "umpr_common.h"
+#include "umpr_internal.h"
+
+namespace {
+
+constexpr int D = 128;  // 2u
+constexpr int AT = 64;  // self_atte_size
+
+__device__ float block_sum4(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// -------------------------------------------------------------------------------------------------- S-Net
+struct SnetFwdParams {
+  const float* X;    // [B][S][L][128]
+  const float* U;    // [B][S][L][64] = tanh(X Ms^T)
+  const float* Ws;   // [64]
+  const float* word_soft; int wl;  // [B][S][wl]
+  float* P;          // [B][S][L]   softmax over tokens (saved)
+  float* wsum;       // [B][S]
+  float* self_atte;  // [B][S][128]
+  float* senti; long ld_senti;  // senti[b*ld + c]
+  int S, L;
+};
+
+__global__ __launch_bounds__(256) void snet_pool_fwd_kernel(SnetFwdParams p) {
+  __shared__ float part[4][D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const float w = p.Ws[lane];
+  float s0 = 0.f, s1 = 0.f;
+  for (int s = wave; s < p.S; s += 4) {
+    const long sent = (long)b * p.S + s;
+    const float* X = p.X + sent * p.L * D;
+    const float* U = p.U + sent * p.L * AT;
+    float e = -INFINITY;  // lane l holds e[l]
+    for (int l = 0; l < p.L; ++l) {
+      const float v = wave_sum(w * U[l * AT + lane]);
+      if (lane == l) e = v;
+    }
+    const float m = wave_max(e);
+    const float ex = lane < p.L ? expf(e - m) : 0.f;
+    const float z = wave_sum(ex);
+    const float pr = ex / z;
+    if (lane < p.L) p.P[sent * p.L + lane] = pr;
+    float a0 = 0.f, a1 = 0.f;
+    for (int l = 0; l < p.L; ++l) {
+      const float pl = __shfl(pr, l, 64);
+      a0 += pl * X[l * D + lane];
+      a1 += pl * X[l * D + 64 + lane];
+    }
+    p.self_atte[sent * D + lane] = a0;
+    p.self_atte[sent * D + 64 + lane] = a1;
+    float ws = 0.f;
+    for (int i = lane; i < p.wl; i += 64) ws += p.word_soft[sent * p.wl + i];
+    ws = wave_sum(ws);
+    if (lane == 0) p.wsum[sent] = ws;
+    s0 += ws * a0; s1 += ws * a1;
+  }
+  part[wave][lane] = s0; part[wave][64 + lane] = s1;
+  __syncthreads();
+  if (tid < D) p.senti[(long)b * p.ld_senti + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+}
+
+struct SnetBwdParams {
+  const float* X; const float* U; const float* Ws; const float* P; const float* wsum; const float* self_atte;
+  const float* d_senti; long ld_ds;   // [B][128] strided rows
+  const float* d_self_atte;           // [B][S][128] or null
+  float* dX;                          // [B][S][L][128]  (= p[l] * d_sa; the GEMM dPre Ms accumulates onto it)
+  float* dPre;                        // [B][S][L][64]
+  float* dWs_part;                    // [B][64]
+  float* d_word_soft; int wl;         // [B][S][wl] or null
+  int S, L;
+};
+
+__global__ __launch_bounds__(256) void snet_pool_bwd_kernel(SnetBwdParams p) {
+  __shared__ float part[4][AT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const float w = p.Ws[lane];
+  const float ds0 = p.d_senti[(long)b * p.ld_ds + lane], ds1 = p.d_senti[(long)b * p.ld_ds + 64 + lane];
+  float dws = 0.f;
+  for (int s = wave; s < p.S; s += 4) {
+    const long sent = (long)b * p.S + s;
+    const float* X = p.X + sent * p.L * D;
+    const float* U = p.U + sent * p.L * AT;
+    const float ws = p.wsum[sent];
+    float g0 = ws * ds0, g1 = ws * ds1;  // d self_atte
+    if (p.d_self_atte) { g0 += p.d_self_atte[sent * D + lane]; g1 += p.d_self_atte[sent * D + 64 + lane]; }
+    const float dwsum = wave_sum(p.self_atte[sent * D + lane] * ds0 + p.self_atte[sent * D + 64 + lane] * ds1);
+    if (p.d_word_soft)
+      for (int i = lane; i < p.wl; i += 64) p.d_word_soft[sent * p.wl + i] = dwsum;
+    const float pr = lane < p.L ? p.P[sent * p.L + lane] : 0.f;
+    float dp = 0.f;  // lane l holds dp[l]
+    for (int l = 0; l < p.L; ++l) {
+      const float v = wave_sum(X[l * D + lane] * g0 + X[l * D + 64 + lane] * g1);
+      if (lane == l) dp = v;
+    }
+    const float dot = wave_sum(pr * dp);
+    const float de = pr * (dp - dot);
+    for (int l = 0; l < p.L; ++l) {
+      const float pl = __shfl(pr, l, 64), del = __shfl(de, l, 64);
+      float* dx = p.dX + (sent * p.L + l) * D;
+      dx[lane] = pl * g0; dx[64 + lane] = pl * g1;
+      const float u = U[l * AT + lane];
+      p.dPre[(sent * p.L + l) * AT + lane] = w * del * (1.f - u * u);
+      dws += del * u;
+    }
+  }
+  part[wave][lane] = dws;
+  __syncthreads();
+  if (tid < AT) p.dWs_part[(long)b * AT + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+}
+
+// -------------------------------------------------------------------------------------------------- C-Net
+// Xcol[r][c*3+dk] = X[r+dk-1][c] inside the sentence, else 0      (kernel_size 3, padding 1)
+__global__ void im2col1d_kernel(const float* __restrict__ X, float* __restrict__ Xcol, long R, int L, int C, int KS) {
+  const long total = R * C * KS;
+  const int pad = (KS - 1) / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int dk = (int)(i % KS);
+    const long q = i / KS;
+    const int c = (int)(q % C);
+    const long r = q / C;
+    const int l = (int)(r % L) + dk - pad;
+    Xcol[i] = (l >= 0 && l < L) ? X[(r + dk - pad) * C + c] : 0.f;
+  }
+}
+// dX[r][c] = sum_dk dXcol[r-dk+1][c*3+dk]
+__global__ void col2im1d_kernel(const float* __restrict__ dXcol, float* __restrict__ dX, long R, int L, int C, int KS,
+                                int accumulate) {
+  const long total = R * C;
+  const int pad = (KS - 1) / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int l = (int)(r % L);
+    float v = 0.f;
+    for (int dk = 0; dk < KS; ++dk) {
+      const int ls = l - dk + pad;
+      if (ls >= 0 && ls < L) v += dXcol[((r - dk + pad) * C + c) * KS + dk];
+    }
+    dX[i] = accumulate ? dX[i] + v : v;
+  }
+}
+
+struct CnetHeadFwdParams {
+  const float* Y;    // [B][S][L][KC] = relu(conv)
+  const float* Wl;   // [V][KC]
+  const float* bl;   // [V]
+  float thr;
+  float* cmax; int* argl;  // [B][S][KC]
+  float* sp;               // [B][S][V]  sigmoid before threshold
+  float* view_p;           // [B][S][V]
+  float* final_;           // [B][V]
+  int S, L, KC, V;
+};
+
+__global__ __launch_bounds__(256) void cnet_head_fwd_kernel(CnetHeadFwdParams p) {
+  extern __shared__ float sm[];  // cm[4][KC], fin[4][V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  float* cm = sm + wave * p.KC;
+  float* fin = sm + 4 * p.KC;
+  for (int v = lane; v < p.V; v += 64) fin[wave * p.V + v] = 0.f;
+  __syncthreads();
+  for (int s0 = 0; s0 < p.S; s0 += 4) {
+    const int s = s0 + wave;
+    const bool on = s < p.S;
+    const long sent = (long)b * p.S + s;
+    if (on) {
+      const float* Y = p.Y + sent * p.L * p.KC;
+      for (int k = lane; k < p.KC; k += 64) {
+        float m = Y[k]; int a = 0;
+        for (int l = 1; l < p.L; ++l) {
+          const float y = Y[l * p.KC + k];
+          if (y > m) { m = y; a = l; }
+        }
+        cm[k] = m;
+        p.cmax[sent * p.KC + k] = m; p.argl[sent * p.KC + k] = a;
+      }
+    }
+    __syncthreads();
+    if (on) {
+      for (int v = 0; v < p.V; ++v) {
+        float a = 0.f;
+        for (int k = lane; k < p.KC; k += 64) a += p.Wl[v * p.KC + k] * cm[k];
+        a = wave_sum(a) + p.bl[v];
+        const float sg = sigmoidf_(a);
+        const float vp = sg < p.thr ? 0.f : sg;
+        if (lane == 0) {
+          p.sp[sent * p.V + v] = sg; p.view_p[sent * p.V + v] = vp;
+          fin[wave * p.V + v] += vp * vp;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int v = tid; v < p.V; v += 256)
+    p.final_[(long)b * p.V + v] = fin[v] + fin[p.V + v] + fin[2 * p.V + v] + fin[3 * p.V + v];
+}
+
+struct CnetHeadBwdParams {
+  const float* cmax; const int* argl; const float* sp; const float* view_p; const float* Wl;
+  const float* d_final;   // [B][V] or null
+  const float* d_view_p;  // [B][S][V] or null
+  float* dY;              // [B][S][L][KC] pre-zeroed
+  float* dWl_part;        // [B][V][KC]
+  float* dbl_part;        // [B][V]
+  int S, L, KC, V;
+};
+
+__global__ __launch_bounds__(256) void cnet_head_bwd_kernel(CnetHeadBwdParams p) {
+  extern __shared__ float sm[];  // dW[4][V*KC], db[4][V], dsig[4][V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const int VK = p.V * p.KC;
+  float* dW = sm + wave * VK;
+  float* db = sm + 4 * VK + wave * p.V;
+  float* dsg = sm + 4 * VK + 4 * p.V + wave * p.V;
+  for (int i = lane; i < VK; i += 64) dW[i] = 0.f;
+  for (int v = lane; v < p.V; v += 64) db[v] = 0.f;
+  __syncthreads();
+  for (int s0 = 0; s0 < p.S; s0 += 4) {
+    const int s = s0 + wave;
+    const bool on = s < p.S;
+    const long sent = (long)b * p.S + s;
+    if (on) {
+      for (int v = lane; v < p.V; v += 64) {
+        const float vp = p.view_p[sent * p.V + v], sg = p.sp[sent * p.V + v];
+        float g = 0.f;
+        if (p.d_view_p) g += p.d_view_p[sent * p.V + v];
+        if (p.d_final) g += 2.f * vp * p.d_final[(long)b * p.V + v];
+        const float d = vp > 0.f ? g * sg * (1.f - sg) : 0.f;  // thresholded entries carry no gradient
+        dsg[v] = d;
+        db[v] += d;
+      }
+    }
+    __syncthreads();
+    if (on) {
+      for (int k = lane; k < p.KC; k += 64) {
+        const float cmv = p.cmax[sent * p.KC + k];
+        float dc = 0.f;
+        for (int v = 0; v < p.V; ++v) {
+          dc += dsg[v] * p.Wl[v * p.KC + k];
+          dW[v * p.KC + k] += dsg[v] * cmv;
+        }
+        if (cmv > 0.f) p.dY[(sent * p.L + p.argl[sent * p.KC + k]) * p.KC + k] = dc;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = tid; i < VK; i += 256) p.dWl_part[(long)b * VK + i] = sm[i] + sm[VK + i] + sm[2 * VK + i] + sm[3 * VK + i];
+  const float* dbb = sm + 4 * VK;
+  for (int v = tid; v < p.V; v += 256)
+    p.dbl_part[(long)b * p.V + v] = dbb[v] + dbb[p.V + v] + dbb[2 * p.V + v] + dbb[3 * p.V + v];
+}
+
+// -------------------------------------------------------------------------------------------------- gate
+struct GateFwdParams {
+  const float* sa;       // [B][S][128] self attention of the ui review (control S-Net)
+  const float* w; const float* bias;   // SS-Net linear [128], [1]
+  const float* view_p;   // [B][S][V]
+  const float* c_out;    // [B][V]
+  float* senti;          // [B][S]
+  float* vs;             // [B][V]
+  float* prefer_pos; float* prefer_neg;  // [B][V]
+  int S, V;
+};
+
+__global__ __launch_bounds__(64) void gate_fwd_kernel(GateFwdParams p) {
+  extern __shared__ float sm[];  // senti[S]
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const float w0 = p.w[lane], w1 = p.w[64 + lane], bb = p.bias[0];
+  for (int s = 0; s < p.S; ++s) {
+    const float* sa = p.sa + ((long)b * p.S + s) * D;
+    const float v = wave_sum(sa[lane] * w0 + sa[64 + lane] * w1) + bb;
+    const float sg = sigmoidf_(v);
+    if (lane == 0) { sm[s] = sg; p.senti[(long)b * p.S + s] = sg; }
+  }
+  __syncthreads();
+  for (int v = lane; v < p.V; v += 64) {
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < p.S; ++s) {
+      const float vp = p.view_p[((long)b * p.S + s) * p.V + v];
+      num += sm[s] * vp * vp; den += vp * vp;
+    }
+    const float vsc = num / (den + 1e-4f);
+    const float qp = vsc > 0.5f ? 1.f : 0.f;
+    const float qpos = vsc < 0.5f ? 0.f : 4.f * (vsc - 0.5f) * (vsc - 0.5f);
+    const float qneg = vsc > 0.5f ? 0.f : 4.f * (0.5f - vsc) * (0.5f - vsc);
+    const float co = p.c_out[(long)b * p.V + v];
+    p.vs[(long)b * p.V + v] = vsc;
+    p.prefer_pos[(long)b * p.V + v] = co * qp * qpos;
+    p.prefer_neg[(long)b * p.V + v] = co * (1.f - qp) * qneg;
+  }
+}
+
+struct GateBwdParams {
+  const float* sa; const float* w; const float* view_p; const float* c_out; const float* senti; const float* vs;
+  const float* d_pp; const float* d_pn;  // [B][V]
+  float* d_sa;       // [B][S][128]
+  float* d_view_p;   // [B][S][V]
+  float* d_c_out;    // [B][V]
+  float* dw_part;    // [B][128]
+  float* db_part;    // [B]
+  int S, V;
+};
+
+__global__ __launch_bounds__(64) void gate_bwd_kernel(GateBwdParams p) {
+  extern __shared__ float sm[];  // dnum[V], dden[V], dsenti[S]
+  const int lane = threadIdx.x, b = blockIdx.x;
+  float* dnum = sm; float* dden = sm + p.V; float* dse = sm + 2 * p.V;
+  for (int v = lane; v < p.V; v += 64) {
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < p.S; ++s) {
+      const float vp = p.view_p[((long)b * p.S + s) * p.V + v];
+      num += p.senti[(long)b * p.S + s] * vp * vp; den += vp * vp;
+    }
+    den += 1e-4f;
+    const float vsc = p.vs[(long)b * p.V + v];
+    const float qp = vsc > 0.5f ? 1.f : 0.f;
+    const float qpos = vsc < 0.5f ? 0.f : 4.f * (vsc - 0.5f) * (vsc - 0.5f);
+    const float qneg = vsc > 0.5f ? 0.f : 4.f * (0.5f - vsc) * (0.5f - vsc);
+    const float dqpos = vsc < 0.5f ? 0.f : 8.f * (vsc - 0.5f);
+    const float dqneg = vsc > 0.5f ? 0.f : -8.f * (0.5f - vsc);
+    const float co = p.c_out[(long)b * p.V + v];
+    const float gpp = p.d_pp[(long)b * p.V + v], gpn = p.d_pn[(long)b * p.V + v];
+    p.d_c_out[(long)b * p.V + v] = gpp * qp * qpos + gpn * (1.f - qp) * qneg;
+    const float dvs = gpp * co * qp * dqpos + gpn * co * (1.f - qp) * dqneg;
+    dnum[v] = dvs / den;
+    dden[v] = -dvs * num / (den * den);
+  }
+  __syncthreads();
+  for (int s = lane; s < p.S; s += 64) {
+    float d = 0.f;
+    const float se = p.senti[(long)b * p.S + s];
+    for (int v = 0; v < p.V; ++v) {
+      const float vp = p.view_p[((long)b * p.S + s) * p.V + v];
+      d += dnum[v] * vp * vp;
+      p.d_view_p[((long)b * p.S + s) * p.V + v] = 2.f * vp * (se * dnum[v] + dden[v]);
+    }
+    dse[s] = d * se * (1.f - se);
+  }
+  __syncthreads();
+  const float w0 = p.w[lane], w1 = p.w[64 + lane];
+  float dw0 = 0.f, dw1 = 0.f, dbs = 0.f;
+  for (int s = 0; s < p.S; ++s) {
+    const float d = dse[s];
+    const float* sa = p.sa + ((long)b * p.S + s) * D;
+    float* dsa = p.d_sa + ((long)b * p.S + s) * D;
+    dw0 += d * sa[lane]; dw1 += d * sa[64 + lane]; dbs += d;
+    dsa[lane] = d * w0; dsa[64 + lane] = d * w1;
+  }
+  p.dw_part[(long)b * D + lane] = dw0; p.dw_part[(long)b * D + 64 + lane] = dw1;
+  if (lane == 0) p.db_part[b] = dbs;
+}
+
+// -------------------------------------------------------------------------------------------------- head
+using HeadParams = UmprHead;
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int B = p.B, V = p.V;
+  if (V > 0) {
+    // pos/neg view embeddings and image embeddings: one wave per dot product of length F
+    const int ndot = 2 * V + B * V;
+    for (int d = wave; d < ndot; d += 4) {
+      float a = 0.f;
+      if (d < 2 * V) {
+        const float* src = (d < V ? p.pos_v + (long)d * p.F : p.neg_v + (long)(d - V) * p.F);
+        for (int i = lane; i < p.F; i += 64) a += src[i] * p.lw[i];
+      } else {
+        const int bv = d - 2 * V;
+        for (int i = lane; i < p.F; i += 64) {
+          float m = 0.f;
+          for (int q = 0; q < p.P; ++q) m += p.vgg[((long)bv * p.P + q) * p.F + i];
+          a += (m / (float)p.P) * p.lw[i];
+        }
+      }
+      a = wave_sum(a) + p.lb[0];
+      if (lane == 0) {
+        if (d < 2 * V) p.posneg_emb[d] = a; else p.img_emb[d - 2 * V] = a;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < B * V; i += 256) {
+      const int v = i % V;
+      const float ie = p.img_emb[i];
+      p.pos_match[i] = tanhf(fabsf(p.posneg_emb[v] - ie));
+      p.neg_match[i] = tanhf(fabsf(p.posneg_emb[V + v] - ie));
+    }
+    __syncthreads();
+  }
+  float se = 0.f;
+  for (int b = wave; b < B; b += 4) {
+    float a = p.rr[(long)b * D + lane] * p.fw[lane] + p.rr[(long)b * D + 64 + lane] * p.fw[64 + lane];
+    for (int v = lane; v < V; v += 64) {
+      const float cc = p.c_u[b * V + v] * p.c_i[b * V + v];
+      a += cc * (1.f - p.pos_match[b * V + v]) * p.fw[D + v] + cc * (1.f - p.neg_match[b * V + v]) * p.fw[D + V + v];
+    }
+    a = wave_sum(a) + p.fb[0];
+    const float pr = fmaxf(a, 0.f);
+    if (lane == 0) {
+      p.z[b] = a; p.pred[b] = pr;
+      const float e = pr - p.labels[b];
+      se += e * e;
+    }
+  }
+  const float loss_r = block_sum4(se, red) / (float)B;
+  float lv = 0.f;
+  if (V > 0) {
+    // mean over the VxV matrix prefer_pos^T pos_match + prefer_neg^T neg_match (contraction over the batch)
+    for (int i = tid; i < V * V; i += 256) {
+      const int v1 = i / V, v2 = i % V;
+      float a = 0.f;
+      for (int b = 0; b < B; ++b)
+        a += p.pp[b * V + v1] * p.pos_match[b * V + v2] + p.pn[b * V + v1] * p.neg_match[b * V + v2];
+      lv += a;
+    }
+    lv = block_sum4(lv, red) / (float)(V * V);
+  }
+  if (tid == 0) {
+    p.loss[0] = loss_r + lv * p.rate; p.loss[1] = loss_r; p.loss[2] = lv;
+  }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
+  extern __shared__ float sm[];  // dz[B], dimg[B*V], ddp[B*V], ddn[B*V], dpos[V], dneg[V]
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int B = p.B, V = p.V, FW = D + 2 * V;
+  float* dz = sm; float* dimg = sm + B; float* ddps = dimg + B * V; float* ddns = ddps + B * V;
+  float* dpos = ddns + B * V; float* dneg = dpos + V;
+  const float gl = p.d_loss[0];
+  for (int b = tid; b < B; b += 256) {
+    float g = gl * 2.f * (p.pred[b] - p.labels[b]) / (float)B;
+    if (p.d_pred) g += p.d_pred[b];
+    dz[b] = p.z[b] > 0.f ? g : 0.f;
+  }
+  __syncthreads();
+  // fusion layer
+  for (int i = tid; i < FW; i += 256) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float f;
+      if (i < D) f = p.rr[(long)b * D + i];
+      else if (i < D + V) { const int v = i - D; f = p.c_u[b * V + v] * p.c_i[b * V + v] * (1.f - p.pos_match[b * V + v]); }
+      else { const int v = i - D - V; f = p.c_u[b * V + v] * p.c_i[b * V + v] * (1.f - p.neg_match[b * V + v]); }
+      a += dz[b] * f;
+    }
+    p.d_fw[i] = a;
+  }
+  {
+    float a = 0.f;
+    for (int b = tid; b < B; b += 256) a += dz[b];
+    a = block_sum4(a, red);
+    if (tid == 0) p.d_fb[0] = a;
+  }
+  for (int i = tid; i < B * D; i += 256) p.d_rr[i] = dz[i / D] * p.fw[i % D];
+  if (V == 0) return;
+  const float sv = gl * p.rate / (float)(V * V);
+  for (int i = tid; i < B * V; i += 256) {
+    const int b = i / V, v = i % V;
+    const float cu = p.c_u[i], ci = p.c_i[i], pm = p.pos_match[i], nm = p.neg_match[i];
+    const float dfp = dz[b] * p.fw[D + v], dfn = dz[b] * p.fw[D + V + v];
+    p.d_cu[i] = dfp * ci * (1.f - pm) + dfn * ci * (1.f - nm);
+    p.d_ci[i] = dfp * cu * (1.f - pm) + dfn * cu * (1.f - nm);
+    float spm = 0.f, snm = 0.f, spp = 0.f, spn = 0.f;
+    for (int q = 0; q < V; ++q) {
+      spm += p.pos_match[b * V + q]; snm += p.neg_match[b * V + q];
+      spp += p.pp[b * V + q]; spn += p.pn[b * V + q];
+    }
+    p.d_pp[i] = sv * spm; p.d_pn[i] = sv * snm;
+    const float dpm = -dfp * cu * ci + sv * spp;
+    const float dnm = -dfn * cu * ci + sv * spn;
+    const float ie = p.img_emb[i];
+    const float dp_ = p.posneg_emb[v] - ie, dn_ = p.posneg_emb[V + v] - ie;
+    const float sgp = dp_ > 0.f ? 1.f : (dp_ < 0.f ? -1.f : 0.f), sgn = dn_ > 0.f ? 1.f : (dn_ < 0.f ? -1.f : 0.f);
+    const float ddp = dpm * (1.f - pm * pm) * sgp, ddn = dnm * (1.f - nm * nm) * sgn;
+    dimg[i] = -(ddp + ddn);
+    ddps[i] = ddp;  // d(pos_emb - img_emb)
+    ddns[i] = ddn;
+  }
+  __syncthreads();
+  for (int v = tid; v < V; v += 256) {
+    float a = 0.f, c = 0.f;
+    for (int b = 0; b < B; ++b) { a += ddps[b * V + v]; c += ddns[b * V + v]; }
+    dpos[v] = a; dneg[v] = c;
+  }
+  __syncthreads();
+  for (int i = tid; i < p.F; i += 256) {
+    const float lwi = p.lw[i];
+    float a = 0.f;
+    for (int bv = 0; bv < B * V; ++bv) {
+      float m = 0.f;
+      for (int q = 0; q < p.P; ++q) m += p.vgg[((long)bv * p.P + q) * p.F + i];
+      a += dimg[bv] * (m / (float)p.P);
+      const float g = dimg[bv] * lwi / (float)p.P;
+      for (int q = 0; q < p.P; ++q) p.d_vgg[((long)bv * p.P + q) * p.F + i] = g;
+    }
+    for (int v = 0; v < V; ++v) {
+      a += dpos[v] * p.pos_v[(long)v * p.F + i] + dneg[v] * p.neg_v[(long)v * p.F + i];
+      p.d_pos_v[(long)v * p.F + i] = dpos[v] * lwi;
+      p.d_neg_v[(long)v * p.F + i] = dneg[v] * lwi;
+    }
+    p.d_lw[i] = a;
+  }
+  {
+    float a = 0.f;
+    for (int i = tid; i < B * V; i += 256) a += dimg[i];
+    for (int v = tid; v < V; v += 256) a += dpos[v] + dneg[v];
+    a = block_sum4(a, red);
+    if (tid == 0) p.d_lb[0] = a;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------- misc
+__global__ void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    gx[i] = gy[i] * (1.f - y[i] * y[i]);
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    gx[i] = y[i] > 0.f ? gy[i] : 0.f;
+}
+__global__ void fill_kernel(float* __restrict__ p, long n, float v) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+// partial[chunk][j] = sum over rows of the chunk
+__global__ void colsum_stage1_kernel(const float* __restrict__ src, long rows, int cols, long ld, int rows_per_chunk,
+                                     float* __restrict__ part) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  const long r1 = min(rows, r0 + rows_per_chunk);
+  float v = 0.f;
+  for (long r = r0; r < r1; ++r) v += src[r * ld + j];
+  part[(long)blockIdx.y * cols + j] = v;
+}
+__global__ void colsum_stage2_kernel(const float* __restrict__ part, int chunks, int cols, float* __restrict__ dst,
+                                     int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  float v = 0.f;
+  for (int c = 0; c < chunks; ++c) v += part[(long)c * cols + j];
+  dst[j] = accumulate ? dst[j] + v : v;
+}
+
+// dropout: keep-mask from a counter hash (seed, element index); y = x * mask / (1-p)
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
+                                   long n, float p, uint64_t seed, int gen) {
+  const float scale = 1.f / (1.f - p);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    uint8_t m;
+    if (gen) {
+      const uint32_t h = hash32((uint32_t)i * 0x9E3779B9U + (uint32_t)seed) ^ hash32((uint32_t)(i >> 32) + (uint32_t)(seed >> 32) + 0x85ebca6bU);
+      const float u = (float)(hash32(h) >> 8) * (1.0f / 16777216.0f);
+      m = u >= p ? 1 : 0;
+      mask[i] = m;
+    } else {
+      m = mask[i];
+    }
+    y[i] = m ? x[i] * scale : 0.f;
+  }
+}
+// gx = gy * mask/(1-p) * [a > 0]   (a = ReLU output feeding the dropout; a may be null)
+__global__ void dropout_bwd_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ mask,
+                                   const float* __restrict__ a, float* __restrict__ gx, long n, float p) {
+  const float scale = 1.f / (1.f - p);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float g = mask ? (mask[i] ? gy[i] * scale : 0.f) : gy[i];
+    if (a && !(a[i] > 0.f)) g = 0.f;
+    gx[i] = g;
+  }
+}
+
+// Adam with coupled L2 exactly as torch.optim.Adam applies it (main.py:22-25):
+//   g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float gscale, float wd, float b1, float b2, float eps,
+                            float step_size, float inv_bc2_sqrt) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float gi = g[i] * gscale + wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+inline int nblocks(long n, int cap = 4096) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+// ---- internal host wrappers --------------------------------------------------------------------------------
+int umpr_fill(float* p, long n, float v, hipStream_t s) {
+  fill_kernel<<<nblocks(n), 256, 0, s>>>(p, n, v);
+  UMPR_LAUNCH_CHECK("fill");
+  return 0;
+}
+int umpr_tanh_bwd(const float* y, const float* gy, float* gx, long n, hipStream_t s) {
+  tanh_bwd_kernel<<<nblocks(n), 256, 0, s>>>(y, gy, gx, n);
+  UMPR_LAUNCH_CHECK("tanh_bwd");
+  return 0;
+}
+int umpr_relu_bwd(const float* y, const float* gy, float* gx, long n, hipStream_t s) {
+  relu_bwd_kernel<<<nblocks(n), 256, 0, s>>>(y, gy, gx, n);
+  UMPR_LAUNCH_CHECK("relu_bwd");
+  return 0;
+}
+size_t umpr_colsum_ws_bytes(long rows, int cols) { return (size_t)cdiv(rows, 256) * cols * sizeof(float); }
+int umpr_colsum(const float* src, long rows, int cols, long ld, float* dst, int accumulate, float* ws, size_t ws_bytes,
+                hipStream_t s) {
+  const int chunks = cdiv(rows, 256);
+  UMPR_REQUIRE(ws_bytes >= (size_t)chunks * cols * sizeof(float), "colsum: workspace too small");
+  colsum_stage1_kernel<<<dim3(cdiv(cols, 64), chunks), 64, 0, s>>>(src, rows, cols, ld, 256, ws);
+  UMPR_LAUNCH_CHECK("colsum1");
+  colsum_stage2_kernel<<<cdiv(cols, 64), 64, 0, s>>>(ws, chunks, cols, dst, accumulate);
+  UMPR_LAUNCH_CHECK("colsum2");
+  return 0;
+}
+int umpr_dropout_fwd_impl(const float* x, float* y, uint8_t* mask, long n, float p, uint64_t seed, int gen, hipStream_t s) {
+  dropout_fwd_kernel<<<nblocks(n), 256, 0, s>>>(x, y, mask, n, p, seed, gen);
+  UMPR_LAUNCH_CHECK("dropout_fwd");
+  return 0;
+}
+int umpr_dropout_bwd_impl(const float* gy, const uint8_t* mask, const float* a, float* gx, long n, float p, hipStream_t s) {
+  dropout_bwd_kernel<<<nblocks(n), 256, 0, s>>>(gy, mask, a, gx, n, p);
+  UMPR_LAUNCH_CHECK("dropout_bwd");
+  return 0;
+}
+int umpr_adam_impl(float* p, const float* g, float* m, float* v, long n, float gscale, float wd, float b1, float b2,
+                   float eps, float step_size, float inv_bc2_sqrt, hipStream_t s) {
+  adam_kernel<<<nblocks(n, 8192), 256, 0, s>>>(p, g, m, v, n, gscale, wd, b1, b2, eps, step_size, inv_bc2_sqrt);
+  UMPR_LAUNCH_CHECK("adam");
+  return 0;
+}
+
+// ---- S-Net ---------------------------------------------------------------------------------------------------
+int umpr_snet_fwd_impl(const float* X, const float* Ms, const float* Ws, const float* word_soft, int wl, int B, int S,
+                       int L, float* U, float* P, float* wsum, float* self_atte, float* senti, long ld_senti,
+                       hipStream_t s) {
+  UMPR_REQUIRE(L <= 64, "snet: sentence length %d > 64 unsupported", L);
+  UmprGemm g;
+  g.A = X; g.lda = D; g.B = Ms; g.ldb = D; g.transB = true; g.C = U; g.ldc = AT; g.M = B * S * L; g.N = AT; g.K = D;
+  g.act = UMPR_ACT_TANH;
+  if (int rc = umpr_gemm(g, s)) return rc;
+  SnetFwdParams p{X, U, Ws, word_soft, wl, P, wsum, self_atte, senti, ld_senti, S, L};
+  snet_pool_fwd_kernel<<<B, 256, 0, s>>>(p);
+  UMPR_LAUNCH_CHECK("snet_pool_fwd");
+  return 0;
+}
+
+size_t umpr_snet_bwd_ws_bytes_impl(int B, int S, int L) {
+  return ((size_t)B * S * L * AT + (size_t)B * AT + (size_t)512 * AT * D) * sizeof(float);
+}
+
+int umpr_snet_bwd_impl(const float* X, const float* Ms, const float* Ws, const float* U, const float* P,
+                       const float* wsum, const float* self_atte, const float* d_senti, long ld_ds,
+                       const float* d_self_atte, int B, int S, int L, int wl, float* dX, float* dMs, float* dWs,
+                       float* d_word_soft, float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(ws_bytes >= umpr_snet_bwd_ws_bytes_impl(B, S, L), "snet_bwd: workspace too small");
+  float* dPre = ws; float* dWs_part = ws + (size_t)B * S * L * AT; float* slab = dWs_part + (size_t)B * AT;
+  SnetBwdParams p{X, U, Ws, P, wsum, self_atte, d_senti, ld_ds, d_self_atte, dX, dPre, dWs_part, d_word_soft, wl, S, L};
+  snet_pool_bwd_kernel<<<B, 256, 0, s>>>(p);
+  UMPR_LAUNCH_CHECK("snet_pool_bwd");
+  const int R = B * S * L;
+  UmprGemm g;  // dX += dPre Ms
+  g.A = dPre; g.lda = AT; g.B = Ms; g.ldb = D; g.C = dX; g.ldc = D; g.M = R; g.N = D; g.K = AT; g.accumulate = true;
+  if (int rc = umpr_gemm(g, s)) return rc;
+  UmprGemm h;  // dMs = dPre^T X
+  h.A = dPre; h.lda = AT; h.transA = true; h.B = X; h.ldb = D; h.C = dMs; h.ldc = D; h.M = AT; h.N = D; h.K = R;
+  h.split_k = 0; h.ws = slab; h.ws_bytes = (size_t)512 * AT * D * sizeof(float);
+  if (int rc = umpr_gemm(h, s)) return rc;
+  colsum_stage2_kernel<<<1, 64, 0, s>>>(dWs_part, B, AT, dWs, 0);
+  UMPR_LAUNCH_CHECK("snet_dWs");
+  return 0;
+}
+
+// ---- C-Net head ------------------------------------------------------------------------------------------------
+size_t umpr_cnet_fwd_ws_bytes(int B, int S, int L, int KS) { return (size_t)B * S * L * D * KS * sizeof(float); }
+
+int umpr_cnet_head_fwd_impl(const float* X, const float* Wc, const float* bc, const float* Wl, const float* bl,
+                            float thr, int B, int S, int L, int KC, int KS, int V, float* Y, float* cmax, int* argl,
+                            float* sp, float* view_p, float* final_, float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(ws_bytes >= umpr_cnet_fwd_ws_bytes(B, S, L, KS), "cnet: workspace too small");
+  const long R = (long)B * S * L;
+  float* Xcol = ws;
+  im2col1d_kernel<<<nblocks(R * D * KS), 256, 0, s>>>(X, Xcol, R, L, D, KS);
+  UMPR_LAUNCH_CHECK("im2col1d");
+  UmprGemm g;
+  g.A = Xcol; g.lda = D * KS; g.B = Wc; g.ldb = D * KS; g.transB = true; g.C = Y; g.ldc = KC; g.M = (int)R; g.N = KC;
+  g.K = D * KS; g.bias = bc; g.bias_mode = 1; g.act = UMPR_ACT_RELU;
+  if (int rc = umpr_gemm(g, s)) return rc;
+  CnetHeadFwdParams p{Y, Wl, bl, thr, cmax, argl, sp, view_p, final_, S, L, KC, V};
+  cnet_head_fwd_kernel<<<B, 256, (4 * KC + 4 * V) * sizeof(float), s>>>(p);
+  UMPR_LAUNCH_CHECK("cnet_head_fwd");
+  return 0;
+}
+
+size_t umpr_cnet_bwd_ws_bytes(int B, int S, int L, int KC, int KS, int V) {
+  const size_t R = (size_t)B * S * L;
+  return (R * KC + 2 * R * D * KS + (size_t)B * V * KC + (size_t)B * V + (size_t)cdiv(R, 256) * KC +
+          (size_t)512 * KC * D * KS) * sizeof(float);
+}
+
+int umpr_cnet_head_bwd_impl(const float* X, const float* Wc, const float* Wl, const float* cmax, const int* argl,
+                            const float* sp, const float* view_p, const float* d_final, const float* d_view_p, int B,
+                            int S, int L, int KC, int KS, int V, float* dX, int accumulate_dX, int accumulate_w, float* dWc,
+                            float* dbc, float* dWl, float* dbl, float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(ws_bytes >= umpr_cnet_bwd_ws_bytes(B, S, L, KC, KS, V), "cnet_bwd: workspace too small");
+  const long R = (long)B * S * L;
+  const int CK = D * KS;
+  float* dY = ws;
+  float* Xcol = dY + R * KC;
+  float* dXcol = Xcol + R * CK;
+  float* dWl_part = dXcol + R * CK;
+  float* dbl_part = dWl_part + (size_t)B * V * KC;
+  float* cs = dbl_part + (size_t)B * V;
+  float* slab = cs + (size_t)cdiv(R, 256) * KC;
+  if (hipMemsetAsync(dY, 0, (size_t)R * KC * sizeof(float), s) != hipSuccess) { umpr_set_error("cnet_bwd: memset"); return -2; }
+  CnetHeadBwdParams p{cmax, argl, sp, view_p, Wl, d_final, d_view_p, dY, dWl_part, dbl_part, S, L, KC, V};
+  cnet_head_bwd_kernel<<<B, 256, (4 * V * KC + 8 * V) * sizeof(float), s>>>(p);
+  UMPR_LAUNCH_CHECK("cnet_head_bwd");
+  colsum_stage2_kernel<<<cdiv(V * KC, 64), 64, 0, s>>>(dWl_part, B, V * KC, dWl, accumulate_w);
+  colsum_stage2_kernel<<<cdiv(V, 64), 64, 0, s>>>(dbl_part, B, V, dbl, accumulate_w);
+  UMPR_LAUNCH_CHECK("cnet_dWl");
+  if (int rc = umpr_colsum(dY, R, KC, KC, dbc, accumulate_w, cs, (size_t)cdiv(R, 256) * KC * sizeof(float), s)) return rc;
+  im2col1d_kernel<<<nblocks(R * CK), 256, 0, s>>>(X, Xcol, R, L, D, KS);
+  UMPR_LAUNCH_CHECK("im2col1d");
+  UmprGemm h;  // dWc[KC][CK] = dY^T Xcol
+  h.A = dY; h.lda = KC; h.transA = true; h.B = Xcol; h.ldb = CK; h.C = dWc; h.ldc = CK; h.M = KC; h.N = CK; h.K = (int)R;
+  h.split_k = 0; h.ws = slab; h.ws_bytes = (size_t)512 * KC * CK * sizeof(float); h.accumulate = accumulate_w != 0;
+  if (int rc = umpr_gemm(h, s)) return rc;
+  UmprGemm g;  // dXcol = dY Wc
+  g.A = dY; g.lda = KC; g.B = Wc; g.ldb = CK; g.C = dXcol; g.ldc = CK; g.M = (int)R; g.N = CK; g.K = KC;
+  if (int rc = umpr_gemm(g, s)) return rc;
+  col2im1d_kernel<<<nblocks(R * D), 256, 0, s>>>(dXcol, dX, R, L, D, KS, accumulate_dX);
+  UMPR_LAUNCH_CHECK("col2im1d");
+  return 0;
+}
+
+// ---- gate ------------------------------------------------------------------------------------------------------
+int umpr_gate_fwd_impl(const float* sa, const float* w, const float* bias, const float* view_p, const float* c_out,
+                       int B, int S, int V, float* senti, float* vs, float* pp, float* pn, hipStream_t s) {
+  GateFwdParams p{sa, w, bias, view_p, c_out, senti, vs, pp, pn, S, V};
+  gate_fwd_kernel<<<B, 64, S * sizeof(float), s>>>(p);
+  UMPR_LAUNCH_CHECK("gate_fwd");
+  return 0;
+}
+size_t umpr_gate_bwd_ws_bytes(int B) { return (size_t)B * (D + 1) * sizeof(float); }
+int umpr_gate_bwd_impl(const float* sa, const float* w, const float* view_p, const float* c_out, const float* senti,
+                       const float* vs, const float* d_pp, const float* d_pn, int B, int S, int V, float* d_sa,
+                       float* d_view_p, float* d_c_out, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(ws_bytes >= umpr_gate_bwd_ws_bytes(B), "gate_bwd: workspace too small");
+  float* dw_part = ws; float* db_part = ws + (size_t)B * D;
+  GateBwdParams p{sa, w, view_p, c_out, senti, vs, d_pp, d_pn, d_sa, d_view_p, d_c_out, dw_part, db_part, S, V};
+  gate_bwd_kernel<<<B, 64, (2 * V + S) * sizeof(float), s>>>(p);
+  UMPR_LAUNCH_CHECK("gate_bwd");
+  colsum_stage2_kernel<<<2, 64, 0, s>>>(dw_part, B, D, dw, 0);
+  colsum_stage2_kernel<<<1, 64, 0, s>>>(db_part, B, 1, db, 0);
+  UMPR_LAUNCH_CHECK("gate_dw");
+  return 0;
+}
+
+// ---- head ------------------------------------------------------------------------------------------------------
+int umpr_head_launch(const UmprHead& p, int backward, hipStream_t s) {
+  if (!backward) {
+    head_fwd_kernel<<<1, 256, 0, s>>>(p);
+    UMPR_LAUNCH_CHECK("head_fwd");
+  } else {
+    const size_t sh = ((size_t)p.B + 3 * (size_t)p.B * p.V + 2 * p.V) * sizeof(float);
+    head_bwd_kernel<<<1, 256, sh, s>>>(p);
+    UMPR_LAUNCH_CHECK("head_bwd");
+  }
+  return 0;
+}

@@ -1,0 +1,111 @@
+// Internal (C++) interfaces between the translation units of libumpr_hip.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct UmprGemm {
+  const float* A = nullptr; long lda = 0; bool transA = false;
+  const float* B = nullptr; long ldb = 0; bool transB = false;
+  float* C = nullptr; long ldc = 0;
+  int M = 0, N = 0, K = 0;
+  const int64_t* gatherA = nullptr;  // !transA: physical row of logical row m (<0: zero row)
+  const int64_t* gatherB = nullptr;  // !transB: physical row of logical k   (<0: zero row)
+  const float* bias = nullptr; int bias_mode = 0;  // 1: bias[n]  2: bias[m]
+  int act = 0; bool accumulate = false; float alpha = 1.0f;
+  int split_k = 1;                   // 0 = auto (needs ws)
+  float* ws = nullptr; size_t ws_bytes = 0;
+};
+int umpr_gemm(const UmprGemm& g, hipStream_t stream);
+
+// small shared launch helpers (util.hip)
+int umpr_fill(float* p, long n, float v, hipStream_t s);
+
+// visual head + fusion + losses (text_ops.hip)
+struct UmprHead {
+  const float* rr;   // [B][128] review_net representation
+  const float* c_u; const float* c_i; const float* pp; const float* pn;  // [B][V] (null when review_net_only)
+  const float* vgg;  // [B*V*P][1000]
+  const float* pos_v; const float* neg_v;  // [V][1000]
+  const float* lw; const float* lb;        // [1000], [1]
+  const float* fw; const float* fb;        // [128 (+2V)], [1]
+  const float* labels;                     // [B]
+  float rate;
+  int B, V, P, F;                          // F = 1000; V = 0 for review_net_only
+  // forward outputs / saved
+  float* pred; float* loss;                // [B], [3] = (loss, loss_r, loss_v)
+  float* z;                                // [B] pre-ReLU
+  float* img_emb; float* pos_match; float* neg_match;  // [B][V]
+  float* posneg_emb;                       // [2][V]
+  // backward inputs / outputs
+  const float* d_loss;                     // [1]
+  const float* d_pred;                     // [B] or null
+  float* d_rr; float* d_cu; float* d_ci; float* d_pp; float* d_pn;
+  float* d_vgg; float* d_pos_v; float* d_neg_v; float* d_lw; float* d_lb; float* d_fw; float* d_fb;
+};
+int umpr_head_launch(const UmprHead& p, int backward, hipStream_t s);
+
+// conv3x3.hip
+int umpr_conv3x3_igemm(const float* x, const float* wm, const float* bias, const float* mask, float* y, int N, int C,
+                       int H, int W, int Cout, int relu, hipStream_t s);
+int umpr_conv3x3_flip_transpose(const float* w, float* wt, int Cout, int Cin, hipStream_t s);
+size_t umpr_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
+                       int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
+int umpr_maxpool2_fwd_impl(const float* x, float* y, long planes, int H, int W, hipStream_t s);
+int umpr_maxpool2_bwd_relu_impl(const float* x, const float* gy, float* gx, long planes, int H, int W, hipStream_t s);
+
+// gru.hip
+int umpr_colsum_rows(const float* src, int rows, long cols, long row_stride, float* dst, int accumulate, hipStream_t s);
+int umpr_gru_recurrent_fwd(const float* gx, const float* whh_f, const float* bhh_f, const float* whh_r,
+                           const float* bhh_r, const int* lengths, const int* order, const int* dst_row, float* out,
+                           float* saved, int N, int L, hipStream_t s);
+int umpr_gru_tiles(int N);
+int umpr_gru_bptt(const float* dout, const float* out, const float* saved, const float* whh_f, const float* whh_r,
+                  const int* lengths, const int* order, const int* dst_row, float* dgx, float* dwhh_slab,
+                  float* dbias_slab, int N, int L, hipStream_t s);
+
+// coattn.hip
+size_t umpr_coattn_fwd_ws_bytes(int B, int SL);
+int umpr_coattn_fwd_impl(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
+                         float* soft_i, float* atte_u, long ld_u, float* atte_i, long ld_i, float* colmax, int* argcol,
+                         float* rowmax, int* argrow, float* ws, size_t ws_bytes, hipStream_t s);
+size_t umpr_coattn_bwd_ws_bytes(int B, int SL);
+int umpr_coattn_bwd_impl(const float* Gu, const float* Gi, const float* M, const float* T, const float* soft_u,
+                         const float* soft_i, const float* colmax, const int* argcol, const float* rowmax,
+                         const int* argrow, const float* d_atte_u, long ld_du, const float* d_atte_i, long ld_di,
+                         const float* d_soft_u, const float* d_soft_i, int B, int SL, float* dGu, float* dGi, float* dM,
+                         int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
+
+// text_ops.hip
+int umpr_tanh_bwd(const float* y, const float* gy, float* gx, long n, hipStream_t s);
+int umpr_relu_bwd(const float* y, const float* gy, float* gx, long n, hipStream_t s);
+size_t umpr_colsum_ws_bytes(long rows, int cols);
+int umpr_colsum(const float* src, long rows, int cols, long ld, float* dst, int accumulate, float* ws, size_t ws_bytes,
+                hipStream_t s);
+int umpr_dropout_fwd_impl(const float* x, float* y, uint8_t* mask, long n, float p, uint64_t seed, int gen, hipStream_t s);
+int umpr_dropout_bwd_impl(const float* gy, const uint8_t* mask, const float* a, float* gx, long n, float p, hipStream_t s);
+int umpr_adam_impl(float* p, const float* g, float* m, float* v, long n, float gscale, float wd, float b1, float b2,
+                   float eps, float step_size, float inv_bc2_sqrt, hipStream_t s);
+int umpr_snet_fwd_impl(const float* X, const float* Ms, const float* Ws, const float* word_soft, int wl, int B, int S,
+                       int L, float* U, float* P, float* wsum, float* self_atte, float* senti, long ld_senti,
+                       hipStream_t s);
+size_t umpr_snet_bwd_ws_bytes_impl(int B, int S, int L);
+int umpr_snet_bwd_impl(const float* X, const float* Ms, const float* Ws, const float* U, const float* P,
+                       const float* wsum, const float* self_atte, const float* d_senti, long ld_ds,
+                       const float* d_self_atte, int B, int S, int L, int wl, float* dX, float* dMs, float* dWs,
+                       float* d_word_soft, float* ws, size_t ws_bytes, hipStream_t s);
+size_t umpr_cnet_fwd_ws_bytes(int B, int S, int L, int KS);
+int umpr_cnet_head_fwd_impl(const float* X, const float* Wc, const float* bc, const float* Wl, const float* bl,
+                            float thr, int B, int S, int L, int KC, int KS, int V, float* Y, float* cmax, int* argl,
+                            float* sp, float* view_p, float* final_, float* ws, size_t ws_bytes, hipStream_t s);
+size_t umpr_cnet_bwd_ws_bytes(int B, int S, int L, int KC, int KS, int V);
+int umpr_cnet_head_bwd_impl(const float* X, const float* Wc, const float* Wl, const float* cmax, const int* argl,
+                            const float* sp, const float* view_p, const float* d_final, const float* d_view_p, int B,
+                            int S, int L, int KC, int KS, int V, float* dX, int accumulate_dX, int accumulate_w, float* dWc,
+                            float* dbc, float* dWl, float* dbl, float* ws, size_t ws_bytes, hipStream_t s);
+int umpr_gate_fwd_impl(const float* sa, const float* w, const float* bias, const float* view_p, const float* c_out,
+                       int B, int S, int V, float* senti, float* vs, float* pp, float* pn, hipStream_t s);
+size_t umpr_gate_bwd_ws_bytes(int B);
+int umpr_gate_bwd_impl(const float* sa, const float* w, const float* view_p, const float* c_out, const float* senti,
+                       const float* vs, const float* d_pp, const float* d_pn, int B, int S, int V, float* d_sa,
+                       float* d_view_p, float* d_c_out, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t s);

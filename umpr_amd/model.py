@@ -1,0 +1,501 @@
+"""UMPR on MI355X: the reference's ``src/model.py`` module tree (same constructor, same ``forward`` signature,
+same state_dict keys) whose arithmetic runs in hand-written gfx950 kernels behind the C ABI of libumpr_hip.so.
+
+The torch ``nn`` modules below (nn.GRU, nn.Conv1d, nn.Linear, ...) are parameter holders only: they give the
+reference's parameter names, shapes and default initialisation; their ``forward`` is never called.  Each
+``torch.autograd.Function`` is one fused region (K-numbers: SURVEY.md section 2a) and calls the C ABI for forward
+and backward.  There is no torch/CPU fallback - without the library or a GPU the model raises.
+
+Reference lines: UMPR.__init__ src/model.py:233-255, UMPR.forward src/model.py:257-278.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch import nn
+
+from ._lib import Workspace, lib, stream_ptr
+
+H = 64          # config.gru_size the kernels are built for
+D = 2 * H
+AT = 64         # config.self_atte_size
+
+
+def _ws(nbytes, device):
+    buf = Workspace.get(max(int(nbytes), 256), device)
+    return buf, buf.numel() * 4
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------- K1-K3
+class _EmbedGru(torch.autograd.Function):
+    """nn.Embedding + ImprovedRnn(nn.GRU bidirectional) (src/model.py:262-264, 12-21)."""
+
+    @staticmethod
+    def forward(ctx, ids, lengths, order, emb, *w):
+        N, L = ids.shape
+        E = emb.shape[1]
+        need = any(ctx.needs_input_grad)
+        out = torch.empty(N, L, D, device=ids.device, dtype=torch.float32)
+        saved = torch.empty(2, N, L, 4, H, device=ids.device, dtype=torch.float32) if need else None
+        ws, wsb = _ws(lib().size("umpr_embed_gru_bidir_ws_bytes", N, L, E), ids.device)
+        w = [_c(x) for x in w]
+        lib().call("umpr_embed_gru_bidir_fwd", ids, emb, E, *w, lengths, order, order, N, L, out, saved, ws, wsb,
+                   stream_ptr())
+        if need:
+            ctx.save_for_backward(ids, lengths, order, emb, w[1], w[5], out, saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, lengths, order, emb, whh_f, whh_r, out, saved = ctx.saved_tensors
+        N, L = ids.shape
+        E = emb.shape[1]
+        dev = ids.device
+        g = [torch.empty(3 * H, E, device=dev), torch.empty(3 * H, H, device=dev), torch.empty(3 * H, device=dev),
+             torch.empty(3 * H, device=dev), torch.empty(3 * H, E, device=dev), torch.empty(3 * H, H, device=dev),
+             torch.empty(3 * H, device=dev), torch.empty(3 * H, device=dev)]
+        ws, wsb = _ws(lib().size("umpr_embed_gru_bidir_ws_bytes", N, L, E), dev)
+        lib().call("umpr_embed_gru_bidir_bwd", ids, emb, E, whh_f, whh_r, lengths, order, order, N, L, _c(dout), out,
+                   saved, *g, ws, wsb, stream_ptr())
+        return (None, None, None, None, *g)
+
+
+# --------------------------------------------------------------------------------------------- K4-K7
+class _ReviewHead(torch.autograd.Function):
+    """R-Net co-attention + S-Net(u) + S-Net(i) + textual matching (src/model.py:50-55, 71-81, 162-168)."""
+
+    @staticmethod
+    def forward(ctx, gru_u, gru_i, S, L, M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i):
+        B, SL, _ = gru_u.shape
+        dev = gru_u.device
+        f = dict(device=dev, dtype=torch.float32)
+        gru_u, gru_i = _c(gru_u), _c(gru_i)
+        T = torch.empty(B, SL, D, **f)
+        soft_u, soft_i = torch.empty(B, SL, **f), torch.empty(B, SL, **f)
+        colmax, rowmax = torch.empty(B, SL, **f), torch.empty(B, SL, **f)
+        argcol = torch.empty(B, SL, device=dev, dtype=torch.int32)
+        argrow = torch.empty(B, SL, device=dev, dtype=torch.int32)
+        repr_u, repr_i = torch.empty(B, 2 * D, **f), torch.empty(B, 2 * D, **f)
+        ws, wsb = _ws(lib().size("umpr_coattention_fwd_ws_bytes", B, SL), dev)
+        st = stream_ptr()
+        lib().call("umpr_coattention_fwd", gru_u, gru_i, M, B, SL, T, soft_u, soft_i, repr_u, 2 * D, repr_i, 2 * D,
+                   colmax, argcol, rowmax, argrow, ws, wsb, st)
+        sn = []
+        for X, Ms, Ws, soft, rep in ((gru_u, Ms_u, Ws_u, soft_u, repr_u), (gru_i, Ms_i, Ws_i, soft_i, repr_i)):
+            U = torch.empty(B, S, L, AT, **f)
+            P = torch.empty(B, S, L, **f)
+            wsum = torch.empty(B, S, **f)
+            sa = torch.empty(B, S, D, **f)
+            lib().call("umpr_snet_fwd", X, Ms, Ws, soft, L, B, S, L, U, P, wsum, sa, rep.data_ptr() + D * 4, 2 * D, st)
+            sn += [U, P, wsum, sa]
+        out = torch.empty(B, D, **f)
+        lib().call("umpr_review_merge_fwd", repr_u, repr_i, W_u, W_i, B, out, st)
+        ctx.dims = (B, S, L)
+        ctx.save_for_backward(gru_u, gru_i, M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i, T, soft_u, soft_i, colmax, argcol,
+                              rowmax, argrow, repr_u, repr_i, out, *sn)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (gru_u, gru_i, M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i, T, soft_u, soft_i, colmax, argcol, rowmax, argrow, repr_u,
+         repr_i, out, U_u, P_u, wsum_u, sa_u, U_i, P_i, wsum_i, sa_i) = ctx.saved_tensors
+        B, S, L = ctx.dims
+        SL = S * L
+        dev = gru_u.device
+        f = dict(device=dev, dtype=torch.float32)
+        st = stream_ptr()
+        d_repr_u, d_repr_i = torch.empty(B, 2 * D, **f), torch.empty(B, 2 * D, **f)
+        dW_u, dW_i = torch.empty_like(W_u), torch.empty_like(W_i)
+        ws, wsb = _ws(lib().size("umpr_review_merge_bwd_ws_bytes", B), dev)
+        lib().call("umpr_review_merge_bwd", repr_u, repr_i, W_u, W_i, out, _c(d_out), B, d_repr_u, d_repr_i, dW_u, dW_i,
+                   ws, wsb, st)
+        dG, dMs, dWs, dsoft = [], [], [], []
+        ws, wsb = _ws(lib().size("umpr_snet_bwd_ws_bytes", B, S, L), dev)
+        for X, Ms, Ws, U, P, wsum, sa, drep in ((gru_u, Ms_u, Ws_u, U_u, P_u, wsum_u, sa_u, d_repr_u),
+                                                (gru_i, Ms_i, Ws_i, U_i, P_i, wsum_i, sa_i, d_repr_i)):
+            dX = torch.empty(B, SL, D, **f)
+            gMs, gWs = torch.empty_like(Ms), torch.empty_like(Ws)
+            ds = torch.empty(B, SL, **f)
+            lib().call("umpr_snet_bwd", X, Ms, Ws, U, P, wsum, sa, drep.data_ptr() + D * 4, 2 * D, None, B, S, L, L, dX,
+                       gMs, gWs, ds, ws, wsb, st)
+            dG.append(dX); dMs.append(gMs); dWs.append(gWs); dsoft.append(ds)
+        dM = torch.empty_like(M)
+        ws, wsb = _ws(lib().size("umpr_coattention_bwd_ws_bytes", B, SL), dev)
+        lib().call("umpr_coattention_bwd", gru_u, gru_i, M, T, soft_u, soft_i, colmax, argcol, rowmax, argrow,
+                   d_repr_u, 2 * D, d_repr_i, 2 * D, dsoft[0], dsoft[1], B, SL, dG[0], dG[1], dM, 1, ws, wsb, st)
+        return dG[0], dG[1], None, None, dM, dMs[0], dWs[0], dMs[1], dWs[1], dW_u, dW_i
+
+
+# --------------------------------------------------------------------------------------------- K8-K9
+class _Control(torch.autograd.Function):
+    """C-Net heads on (ui, user, item) + control S-Net + SS-Net gate (src/model.py:118-125, 179-198)."""
+
+    @staticmethod
+    def forward(ctx, g_ui, g_u, g_i, dims, thr, Wc, bc, Wl, bl, Ms, Ws, ssW, ssb):
+        B, S_ui, L_ui, S, L = dims
+        KC, _, KS = Wc.shape
+        V = Wl.shape[0]
+        dev = g_ui.device
+        f = dict(device=dev, dtype=torch.float32)
+        st = stream_ptr()
+        g_ui, g_u, g_i = _c(g_ui), _c(g_u), _c(g_i)
+        saved = []
+        finals = []
+        for X, s, l in ((g_ui, S_ui, L_ui), (g_u, S, L), (g_i, S, L)):
+            Y = torch.empty(B, s, l, KC, **f)
+            cmax = torch.empty(B, s, KC, **f)
+            argl = torch.empty(B, s, KC, device=dev, dtype=torch.int32)
+            sp, vp = torch.empty(B, s, V, **f), torch.empty(B, s, V, **f)
+            fin = torch.empty(B, V, **f)
+            ws, wsb = _ws(lib().size("umpr_cnet_head_fwd_ws_bytes", B, s, l, KS), dev)
+            lib().call("umpr_cnet_head_fwd", X, Wc, bc, Wl, bl, float(thr), B, s, l, KC, KS, V, Y, cmax, argl, sp, vp,
+                       fin, ws, wsb, st)
+            saved += [cmax, argl, sp, vp]
+            finals.append(fin)
+        view_p, c_out = saved[3], finals[0]
+        U = torch.empty(B, S_ui, L_ui, AT, **f)
+        P = torch.empty(B, S_ui, L_ui, **f)
+        wsum = torch.empty(B, S_ui, **f)
+        sa = torch.empty(B, S_ui, D, **f)
+        senti_unused = torch.empty(B, D, **f)
+        lib().call("umpr_snet_fwd", g_ui, Ms, Ws, view_p, V, B, S_ui, L_ui, U, P, wsum, sa, senti_unused, D, st)
+        senti, vs = torch.empty(B, S_ui, **f), torch.empty(B, V, **f)
+        pp, pn = torch.empty(B, V, **f), torch.empty(B, V, **f)
+        lib().call("umpr_control_gate_fwd", sa, ssW, ssb, view_p, c_out, B, S_ui, V, senti, vs, pp, pn, st)
+        ctx.dims = dims
+        ctx.save_for_backward(g_ui, g_u, g_i, Wc, Wl, Ms, Ws, ssW, c_out, U, P, wsum, sa, senti, vs, *saved)
+        return finals[1], finals[2], pp, pn
+
+    @staticmethod
+    def backward(ctx, d_cu, d_ci, d_pp, d_pn):
+        (g_ui, g_u, g_i, Wc, Wl, Ms, Ws, ssW, c_out, U, P, wsum, sa, senti, vs, *saved) = ctx.saved_tensors
+        B, S_ui, L_ui, S, L = ctx.dims
+        KC, _, KS = Wc.shape
+        V = Wl.shape[0]
+        dev = g_ui.device
+        f = dict(device=dev, dtype=torch.float32)
+        st = stream_ptr()
+        zeros = lambda *s: torch.zeros(*s, **f)
+        d_cu = _c(d_cu) if d_cu is not None else zeros(B, V)
+        d_ci = _c(d_ci) if d_ci is not None else zeros(B, V)
+        d_pp = _c(d_pp) if d_pp is not None else zeros(B, V)
+        d_pn = _c(d_pn) if d_pn is not None else zeros(B, V)
+        view_p = saved[3]
+        d_sa = torch.empty(B, S_ui, D, **f)
+        d_vp = torch.empty(B, S_ui, V, **f)
+        d_cout = torch.empty(B, V, **f)
+        dssW, dssb = torch.empty_like(ssW), torch.empty(1, **f)
+        ws, wsb = _ws(lib().size("umpr_control_gate_bwd_ws_bytes", B), dev)
+        lib().call("umpr_control_gate_bwd", sa, ssW, view_p, c_out, senti, vs, d_pp, d_pn, B, S_ui, V, d_sa, d_vp,
+                   d_cout, dssW, dssb, ws, wsb, st)
+        dX_ui = torch.empty(B, S_ui * L_ui, D, **f)
+        dMs, dWs = torch.empty_like(Ms), torch.empty_like(Ws)
+        ws, wsb = _ws(lib().size("umpr_snet_bwd_ws_bytes", B, S_ui, L_ui), dev)
+        lib().call("umpr_snet_bwd", g_ui, Ms, Ws, U, P, wsum, sa, zeros(B, D), D, d_sa, B, S_ui, L_ui, V, dX_ui, dMs,
+                   dWs, None, ws, wsb, st)
+        dWc, dbc = torch.empty_like(Wc), torch.empty(KC, **f)
+        dWl, dbl = torch.empty_like(Wl), torch.empty(V, **f)
+        dX_u, dX_i = torch.empty(B, S * L, D, **f), torch.empty(B, S * L, D, **f)
+        calls = ((g_ui, S_ui, L_ui, saved[0:4], d_cout, d_vp, dX_ui, 1, 0),
+                 (g_u, S, L, saved[4:8], d_cu, None, dX_u, 0, 1),
+                 (g_i, S, L, saved[8:12], d_ci, None, dX_i, 0, 1))
+        for X, s, l, (cmax, argl, sp, vp), dfin, dvp, dX, accx, accw in calls:
+            ws, wsb = _ws(lib().size("umpr_cnet_head_bwd_ws_bytes", B, s, l, KC, KS, V), dev)
+            lib().call("umpr_cnet_head_bwd", X, Wc, Wl, cmax, argl, sp, vp, dfin, dvp, B, s, l, KC, KS, V, dX, accx,
+                       accw, dWc, dbc, dWl, dbl, ws, wsb, st)
+        return dX_ui, dX_u, dX_i, None, None, dWc, dbc, dWl, dbl, dMs, dWs, dssW, dssb.reshape(1)
+
+
+# --------------------------------------------------------------------------------------------- K10
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr, ctypes.cast(arr, ctypes.c_void_p)
+
+
+class _VGG16(torch.autograd.Function):
+    """torchvision.models.vgg16 configuration D (call site src/model.py:204-207,217)."""
+
+    @staticmethod
+    def forward(ctx, images, train, masks_in, seed, *params):
+        n = images.shape[0]
+        assert tuple(images.shape[1:]) == (3, 224, 224), "VGG16 kernels take 3x224x224 images (src/dataset.py:146)"
+        dev = images.device
+        images = _c(images)
+        params = [_c(p) for p in params]
+        acts = torch.empty(lib().size("umpr_vgg16_act_bytes", n) // 4, device=dev, dtype=torch.float32)
+        use_masks = masks_in is not None
+        masks = _c(masks_in) if use_masks else torch.empty(2, n, 4096, device=dev, dtype=torch.uint8)
+        out = torch.empty(n, 1000, device=dev, dtype=torch.float32)
+        ws, wsb = _ws(lib().size("umpr_vgg16_fwd_ws_bytes", n), dev)
+        keep, parr = _ptr_array(params)
+        lib().call("umpr_vgg16_fwd", images, parr, n, int(train), int(use_masks), int(seed), acts, masks, out, ws, wsb,
+                   stream_ptr())
+        ctx.dropout = bool(train) or use_masks
+        ctx.save_for_backward(images, acts, masks, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        images, acts, masks, *params = ctx.saved_tensors
+        n = images.shape[0]
+        dev = images.device
+        grads = [torch.empty_like(p) for p in params]
+        ws, wsb = _ws(lib().size("umpr_vgg16_ws_bytes", n), dev)
+        keep_p, parr = _ptr_array(params)
+        keep_g, garr = _ptr_array(grads)
+        lib().call("umpr_vgg16_bwd", images, parr, n, int(ctx.dropout), acts, masks, _c(d_out), garr, ws, wsb,
+                   stream_ptr())
+        return (None, None, None, None, *grads)
+
+
+# --------------------------------------------------------------------------------------------- K11-K12
+class _Head(torch.autograd.Function):
+    """Visual head + linear_fusion + MSE / loss_v (src/model.py:218-228, 267-277)."""
+
+    @staticmethod
+    def forward(ctx, rr, c_u, c_i, pp, pn, vgg, pos_v, neg_v, lw, lb, fw, fb, labels, rate, V, Pc):
+        B = rr.shape[0]
+        dev = rr.device
+        f = dict(device=dev, dtype=torch.float32)
+        ctx.set_materialize_grads(False)
+        pred, loss, z = torch.empty(B, **f), torch.empty(3, **f), torch.empty(B, **f)
+        nv = max(V, 1)
+        img_emb, pm, nm = torch.empty(B, nv, **f), torch.empty(B, nv, **f), torch.empty(B, nv, **f)
+        pne = torch.empty(2, nv, **f)
+        rr = _c(rr)
+        args = [(_c(t) if t is not None else None) for t in (c_u, c_i, pp, pn, vgg, pos_v, neg_v, lw, lb)]
+        lib().call("umpr_head_fwd", rr, *args, fw, fb, labels, float(rate), B, V, Pc, pred, loss, z, img_emb, pm, nm,
+                   pne, stream_ptr())
+        ctx.meta = (float(rate), B, V, Pc)
+        ctx.opt = [t is not None for t in args]
+        keep = [t if t is not None else torch.empty(0, **f) for t in args]
+        ctx.save_for_backward(rr, *keep, fw, labels, pred, z, img_emb, pm, nm, pne)
+        terms = loss[1:]
+        ctx.mark_non_differentiable(terms)
+        return pred, loss[0], terms
+
+    @staticmethod
+    def backward(ctx, d_pred, d_loss, _unused):
+        rr, c_u, c_i, pp, pn, vgg, pos_v, neg_v, lw, lb, fw, labels, pred, z, img_emb, pm, nm, pne = ctx.saved_tensors
+        rate, B, V, Pc = ctx.meta
+        dev = rr.device
+        f = dict(device=dev, dtype=torch.float32)
+        if d_loss is None:
+            d_loss = torch.zeros((), **f)
+        d_loss = d_loss.reshape(1).contiguous()
+        d_pred = _c(d_pred) if d_pred is not None else None
+        d_rr = torch.empty_like(rr)
+        d_fw, d_fb = torch.empty_like(fw), torch.empty(1, **f)
+        if V > 0:
+            d_cu, d_ci, d_pp, d_pn = (torch.empty(B, V, **f) for _ in range(4))
+            d_vgg = torch.empty_like(vgg)
+            d_pos, d_neg = torch.empty_like(pos_v), torch.empty_like(neg_v)
+            d_lw, d_lb = torch.empty_like(lw), torch.empty(1, **f)
+        else:
+            d_cu = d_ci = d_pp = d_pn = d_vgg = d_pos = d_neg = d_lw = d_lb = None
+        opt = lambda t: t if (t is not None and t.numel() > 0) else None
+        lib().call("umpr_head_bwd", rr, opt(c_u), opt(c_i), opt(pp), opt(pn), opt(vgg), opt(pos_v), opt(neg_v), opt(lw),
+                   fw, labels, rate, B, V, Pc, pred, z, img_emb, pm, nm, pne, d_loss, d_pred, d_rr, d_cu, d_ci, d_pp,
+                   d_pn, d_vgg, d_pos, d_neg, d_lw, d_lb, d_fw, d_fb, stream_ptr())
+        return d_rr, d_cu, d_ci, d_pp, d_pn, d_vgg, d_pos, d_neg, d_lw, d_lb, d_fw, d_fb, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------- module tree
+class ImprovedRnn(nn.Module):
+    """Parameter holder with the reference's name ``gru.module.*`` (src/model.py:6-10)."""
+
+    def __init__(self, module, *args, **kwargs):
+        assert module is nn.GRU, "the MI355X path implements the GRU the reference instantiates"
+        super().__init__()
+        self.module = module(*args, **kwargs)
+        assert self.module.hidden_size == H and self.module.bidirectional and self.module.num_layers == 1, \
+            f"kernels are built for gru_size={H} (config.py:34), bidirectional, one layer"
+
+    def weights(self):
+        m = self.module
+        return (m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0, m.weight_ih_l0_reverse,
+                m.weight_hh_l0_reverse, m.bias_ih_l0_reverse, m.bias_hh_l0_reverse)
+
+    def forward(self, ids, lengths_dev, order_dev, emb):
+        """ids [N,L] int64 on device; lengths/order int32 on device -> [N, L, 128]."""
+        return _EmbedGru.apply(ids, lengths_dev, order_dev, emb, *self.weights())
+
+
+class RNet(nn.Module):
+    def __init__(self, gru_in, gru_out):
+        super().__init__()
+        self.gru = ImprovedRnn(nn.GRU, input_size=gru_in, hidden_size=gru_out, batch_first=True, bidirectional=True)
+        self.M = nn.Parameter(torch.randn(2 * gru_out, 2 * gru_out))
+
+
+class SNet(nn.Module):
+    def __init__(self, self_atte_size, repr_size):
+        super().__init__()
+        assert self_atte_size == AT and repr_size == D, f"kernels are built for self_atte_size={AT}, repr 2u={D}"
+        self.Ms = nn.Parameter(torch.randn(self_atte_size, repr_size))
+        self.Ws = nn.Parameter(torch.randn(1, self_atte_size))
+
+
+class CNet(nn.Module):
+    def __init__(self, gru_in, gru_out, k_count, k_size, view_size, threshold=0.35):
+        super().__init__()
+        self.threshold = threshold
+        self.gru = ImprovedRnn(nn.GRU, input_size=gru_in, hidden_size=gru_out, batch_first=True, bidirectional=True)
+        self.cnn = nn.Sequential(nn.Conv1d(2 * gru_out, k_count, k_size, padding=(k_size - 1) // 2), nn.ReLU())
+        self.linear = nn.Sequential(nn.Linear(k_count, view_size), nn.Sigmoid())
+
+
+class SSNet(nn.Module):
+    def __init__(self, input_size):
+        super().__init__()
+        self.linear = nn.Sequential(nn.Linear(input_size, 1), nn.Sigmoid())
+
+
+class ReviewNet(nn.Module):
+    def __init__(self, emb_size, gru_size, atte_size):
+        super().__init__()
+        self.r_net = RNet(emb_size, gru_size)
+        self.s_net_u = SNet(atte_size, gru_size * 2)
+        self.s_net_i = SNet(atte_size, gru_size * 2)
+        self.linear_u = nn.Linear(gru_size * 4, gru_size * 2, bias=False)
+        self.linear_i = nn.Linear(gru_size * 4, gru_size * 2, bias=False)
+
+
+class ControlNet(nn.Module):
+    def __init__(self, emb_size, gru_size, k_count, k_size, view_size, threshold, atte_size):
+        super().__init__()
+        self.c_net = CNet(emb_size, gru_size, k_count, k_size, view_size, threshold)
+        self.s_net = SNet(atte_size, repr_size=gru_size * 2)
+        self.ss_net = SSNet(input_size=gru_size * 2)
+
+
+_VGG_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+
+
+class VGG16(nn.Module):
+    """Layer list of torchvision's vgg16 (cfg "D") so that state_dict keys match ``features.N`` / ``classifier.N``."""
+
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        layers, cin = [], 3
+        for v in _VGG_CFG:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(),
+                                        nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, num_classes))
+        for m in self.modules():  # torchvision's non-pretrained initialisation
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+        self.dropout_masks = None  # optional injected keep-masks uint8 [2][n][4096] (parity tests)
+        self._calls = 0
+
+    def param_list(self):
+        ps = []
+        for m in self.features:
+            if isinstance(m, nn.Conv2d):
+                ps += [m.weight, m.bias]
+        for m in self.classifier:
+            if isinstance(m, nn.Linear):
+                ps += [m.weight, m.bias]
+        return ps
+
+    def forward(self, images):
+        self._calls += 1
+        seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
+        return _VGG16.apply(images, self.training, self.dropout_masks, seed, *self.param_list())
+
+
+class VisualNet(nn.Module):
+    def __init__(self, view_size, vgg_out=1000, vgg_weights=None):
+        super().__init__()
+        # The reference asks torchvision for ImageNet weights (pretrained=True, src/model.py:205): a network fetch.
+        # Offline the stack is randomly initialised; pass vgg_weights=<local vgg16 state_dict .pth> to load a file.
+        self.vgg16 = nn.Sequential(VGG16(vgg_out))
+        if vgg_weights:
+            self.vgg16[0].load_state_dict(torch.load(vgg_weights, map_location="cpu", weights_only=True))
+        self.pos_v_emb = nn.Parameter(torch.randn(view_size, vgg_out))
+        self.neg_v_emb = nn.Parameter(torch.randn(view_size, vgg_out))
+        self.linear = nn.Linear(vgg_out, 1)
+
+
+class UMPR(nn.Module):
+    def __init__(self, config, word_emb):
+        super().__init__()
+        self.review_net_only = config.review_net_only
+        self.loss_v_rate = config.loss_v_rate
+        self.embedding = nn.Embedding.from_pretrained(torch.Tensor(word_emb))
+        E = self.embedding.embedding_dim
+        self.review_net = ReviewNet(E, config.gru_size, config.self_atte_size)
+        if config.review_net_only:
+            self.linear_fusion = nn.Sequential(nn.Linear(config.gru_size * 2, 1), nn.ReLU())
+        else:
+            view_size = len(config.views)
+            self.control_net = ControlNet(E, config.gru_size, config.kernel_count, config.kernel_size, view_size,
+                                          config.threshold, config.self_atte_size)
+            self.visual_net = VisualNet(view_size, vgg_weights=getattr(config, "vgg_weights", None))
+            self.linear_fusion = nn.Sequential(nn.Linear(config.gru_size * 2 + view_size + view_size, 1), nn.ReLU())
+        self.last_loss_terms = None
+
+    @staticmethod
+    def _host_perm(lengths, device):
+        """lengths stay on the host (src/model.py:18 ``lengths.cpu()``): the descending, NON-stable torch.sort that
+        pack_padded_sequence runs defines the sentence permutation (SURVEY.md header fact 1)."""
+        flat = lengths.reshape(-1).cpu()
+        _, sorted_indices = torch.sort(flat, descending=True)
+        both = torch.stack([flat.to(torch.int32), sorted_indices.to(torch.int32)])
+        both = both.to(device, non_blocking=True)
+        return both[0], both[1]
+
+    def forward(self, user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels):
+        device = self.embedding.weight.device
+        if device.type != "cuda":
+            raise RuntimeError("umpr_amd.UMPR runs on an MI355X only (no CPU fallback): move the module to a cuda device")
+        user_reviews, item_reviews, ui_reviews = [_c(v.to(device)) for v in (user_reviews, item_reviews, ui_reviews)]
+        photos, labels = [v.to(device) for v in (photos, labels)]
+        labels = _c(labels.float())
+        emb = self.embedding.weight
+        B, S, L = user_reviews.shape
+        _, S_ui, L_ui = ui_reviews.shape
+        lu, ou = self._host_perm(u_lengths, device)
+        li, oi = self._host_perm(i_lengths, device)
+        rn = self.review_net
+        gru_u = rn.r_net.gru(user_reviews.view(B * S, L), lu, ou, emb).view(B, S * L, D)
+        gru_i = rn.r_net.gru(item_reviews.view(B * S, L), li, oi, emb).view(B, S * L, D)
+        rr = _ReviewHead.apply(gru_u, gru_i, S, L, rn.r_net.M, rn.s_net_u.Ms, rn.s_net_u.Ws, rn.s_net_i.Ms,
+                               rn.s_net_i.Ws, rn.linear_u.weight, rn.linear_i.weight)
+        fus = self.linear_fusion[0]
+        if self.review_net_only:
+            pred, loss, terms = _Head.apply(rr, None, None, None, None, None, None, None, None, None, fus.weight,
+                                            fus.bias, labels, 0.0, 0, 0)
+            self.last_loss_terms = terms
+            return pred, loss
+        cn = self.control_net
+        lui, oui = self._host_perm(ui_lengths, device)
+        c_ui = cn.c_net.gru(ui_reviews.view(B * S_ui, L_ui), lui, oui, emb).view(B, S_ui * L_ui, D)
+        c_u = cn.c_net.gru(user_reviews.view(B * S, L), lu, ou, emb).view(B, S * L, D)
+        c_i = cn.c_net.gru(item_reviews.view(B * S, L), li, oi, emb).view(B, S * L, D)
+        cu, ci, pp, pn = _Control.apply(c_ui, c_u, c_i, (B, S_ui, L_ui, S, L), cn.c_net.threshold,
+                                        cn.c_net.cnn[0].weight, cn.c_net.cnn[0].bias, cn.c_net.linear[0].weight,
+                                        cn.c_net.linear[0].bias, cn.s_net.Ms, cn.s_net.Ws, cn.ss_net.linear[0].weight,
+                                        cn.ss_net.linear[0].bias)
+        vn = self.visual_net
+        V, Pc = photos.shape[1], photos.shape[2]
+        vgg = vn.vgg16[0](photos.reshape(B * V * Pc, *photos.shape[3:]).float())
+        pred, loss, terms = _Head.apply(rr, cu, ci, pp, pn, vgg, vn.pos_v_emb, vn.neg_v_emb, vn.linear.weight,
+                                        vn.linear.bias, fus.weight, fus.bias, labels, self.loss_v_rate, V, Pc)
+        self.last_loss_terms = terms
+        return pred, loss
