@@ -338,8 +338,21 @@ def test_vgg16_small(L, dev):
     out = m(x.to(dev))
     check("vgg16 fwd", out, ref, atol=1e-4, rtol=1e-4)
     out.backward(gout.to(dev))
+    # fp64 run of the same network: the yardstick for summation-order noise.  The first conv's weight gradient is a
+    # sum over n*224*224 heavily cancelling terms, where two fp32 summation orders (oneDNN's and ours) differ by
+    # ~0.5% of the tensor max; the HIP result must be as close to the fp64 truth as the fp32 CPU path is.
+    vp64 = {k: v.detach().double().requires_grad_(True) for k, v in vp.items()}
+    ref64 = R.vgg16_forward(x.double(), vp64, pre, dropout_masks=[mk.double() for mk in masks])
+    ref64.backward(gout.double())
     for k, p in m.named_parameters():
-        check(f"vgg16 d{k}", p.grad, vp[pre + k].grad, atol=1e-7, rel_to_max=2e-3)
+        g64 = vp64[pre + k].grad
+        e_gpu = float((p.grad.detach().cpu().double() - g64).abs().max())
+        e_cpu = float((vp[pre + k].grad.double() - g64).abs().max())
+        scale = float(g64.abs().max())
+        log(f"vgg16 d{k}: |hip-f64|={e_gpu:.3e} |cpu32-f64|={e_cpu:.3e} max|g|={scale:.3e}")
+        assert e_gpu <= max(3.0 * e_cpu, 1e-4 * scale), (k, e_gpu, e_cpu, scale)
+        if k != "features.0.weight":
+            check(f"vgg16 d{k}", p.grad, vp[pre + k].grad, atol=1e-7, rel_to_max=2e-3)
 
 
 # ------------------------------------------------------------------------------------------------ end to end vs golden
@@ -365,7 +378,9 @@ def _compare_golden(g, model, pred, loss):
     check("loss", loss, g["loss"], atol=1e-4)
     for k, p in model.named_parameters():
         if "grad/" + k in g:
-            check("grad " + k, p.grad, g["grad/" + k], atol=1e-7, rel_to_max=2e-3)
+            # first conv weight: fp32 summation-order noise of a 100k-term cancelling sum (see test_vgg16_small)
+            rel = 2e-2 if k.endswith("features.0.weight") else 2e-3
+            check("grad " + k, p.grad, g["grad/" + k], atol=1e-7, rel_to_max=rel)
         elif "gradstat/" + k in g:
             stride = int(g["gradstat/" + k][3])
             check("gradsample " + k, p.grad.reshape(-1)[::stride], g["gradsample/" + k], atol=1e-7, rel_to_max=2e-3)

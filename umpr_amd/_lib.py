@@ -56,6 +56,9 @@ SIGNATURES = {
     "umpr_head_fwd": ("pppppppppppppfiiipppppppp", "i"),
     "umpr_head_bwd": ("pppppppppppfiiippppppppppppppppppppp", "i"),
     "umpr_adam_step": ("ppppldddddldp", "i"),
+    "umpr_profile_enable": ("i", "i"),
+    "umpr_profile_reset": ("", "i"),
+    "umpr_profile_read": ("ippp", "i"),
 }
 
 

@@ -2,6 +2,8 @@
 #include <math.h>
 #include <stdarg.h>
 
+#include <vector>
+
 #include "../../include/umpr_hip.h"
 #include "umpr_common.h"
 #include "umpr_internal.h"
@@ -12,6 +14,29 @@ void umpr_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---- profiling registry -------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t e0, e1; int family; double work; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<ProfRec> g_prof_pool;
+double g_prof_ms[UMPR_K_COUNT] = {0}, g_prof_work[UMPR_K_COUNT] = {0};
+long g_prof_n[UMPR_K_COUNT] = {0};
+}  // namespace
+UmprProfScope::UmprProfScope(int family, double work, hipStream_t s) : idx(-1), stream(s) {
+  if (!g_prof_on) return;
+  ProfRec r;
+  if (!g_prof_pool.empty()) { r = g_prof_pool.back(); g_prof_pool.pop_back(); }
+  else { (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1); }
+  r.family = family; r.work = work;
+  (void)hipEventRecord(r.e0, s);
+  g_prof.push_back(r);
+  idx = (int)g_prof.size() - 1;
+}
+UmprProfScope::~UmprProfScope() {
+  if (idx >= 0) (void)hipEventRecord(g_prof[idx].e1, stream);
 }
 
 namespace {
@@ -419,6 +444,30 @@ int umpr_head_bwd(const float* rr, const float* c_u, const float* c_i, const flo
   h.d_vgg = d_vgg; h.d_pos_v = d_pos_v; h.d_neg_v = d_neg_v; h.d_lw = d_lin_w; h.d_lb = d_lin_b; h.d_fw = d_fus_w;
   h.d_fb = d_fus_b;
   return umpr_head_launch(h, 1, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+int umpr_profile_enable(int on) { g_prof_on = on != 0; return 0; }
+int umpr_profile_reset(void) {
+  for (auto& r : g_prof) g_prof_pool.push_back(r);
+  g_prof.clear();
+  for (int i = 0; i < UMPR_K_COUNT; ++i) { g_prof_ms[i] = 0; g_prof_work[i] = 0; g_prof_n[i] = 0; }
+  return 0;
+}
+int umpr_profile_read(int family, double* total_ms, double* total_work, long* launches) {
+  UMPR_REQUIRE(family >= 0 && family < UMPR_K_COUNT, "profile_read: bad family %d", family);
+  for (auto& r : g_prof) {  // fold finished records
+    if (hipEventSynchronize(r.e1) != hipSuccess) { umpr_set_error("profile_read: event sync failed"); return -2; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    g_prof_ms[r.family] += ms; g_prof_work[r.family] += r.work; g_prof_n[r.family] += 1;
+    g_prof_pool.push_back(r);
+  }
+  g_prof.clear();
+  if (total_ms) *total_ms = g_prof_ms[family];
+  if (total_work) *total_work = g_prof_work[family];
+  if (launches) *launches = g_prof_n[family];
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ Adam

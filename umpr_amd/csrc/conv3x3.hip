@@ -371,6 +371,7 @@ int umpr_conv3x3_igemm(const float* x, const float* wm, const float* bias, const
   UMPR_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3: bad shape");
   ConvParams p{x, wm, bias, mask, y, N, C, H, W, Cout, relu};
   const long NP = (long)N * H * W;
+  UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * Cout * C * 9, s);
   if (Cout <= 64) {
     dim3 grid(cdiv(NP, 128), cdiv(Cout, 64));
     conv3x3_igemm_kernel<64, 128><<<grid, 256, 0, s>>>(p);
@@ -422,7 +423,10 @@ int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, in
   p.slab = ws;
   p.bslab = db ? ws + (size_t)splits * 9 * Cout * Cin : nullptr;
   dim3 grid(cdiv(Cin, 64), cdiv(Cout, 64), splits);
-  conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(p);
+  {
+    UmprProfScope prof(UMPR_K_CONV_WGRAD, 2.0 * N * H * W * Cout * Cin * 9, s);
+    conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(p);
+  }
   UMPR_LAUNCH_CHECK("conv3x3_wgrad");
   const long total = (long)9 * Cout * Cin + (db ? Cout : 0);
   int blocks = (int)((total + 255) / 256);

@@ -183,6 +183,7 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   split = g.K > 0 ? cdiv(g.K, kps) : 1;
   p.split_k = split; p.k_per_split = kps; p.ws = g.ws;
   dim3 grid(tn, tm, split);
+  UmprProfScope prof(UMPR_K_GEMM, 2.0 * g.M * g.N * g.K, stream);
   if (BM == 128 && BN == 128) launch_tile<128, 128>(p, g.transA, g.transB, grid, stream);
   else if (BM == 64 && BN == 128) launch_tile<64, 128>(p, g.transA, g.transB, grid, stream);
   else if (BM == 128 && BN == 64) launch_tile<128, 64>(p, g.transA, g.transB, grid, stream);

@@ -109,3 +109,12 @@ size_t umpr_gate_bwd_ws_bytes(int B);
 int umpr_gate_bwd_impl(const float* sa, const float* w, const float* view_p, const float* c_out, const float* senti,
                        const float* vs, const float* d_pp, const float* d_pn, int B, int S, int V, float* d_sa,
                        float* d_view_p, float* d_c_out, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t s);
+
+// ---- in-library kernel timing (bench.py roofline): HIP events recorded on the launch stream around the kernels of
+// one family while profiling is enabled.  Zero cost when disabled.
+enum UmprKernelFamily { UMPR_K_CONV_IGEMM = 0, UMPR_K_CONV_WGRAD = 1, UMPR_K_GEMM = 2, UMPR_K_GRU = 3, UMPR_K_COUNT = 4 };
+struct UmprProfScope {
+  UmprProfScope(int family, double work, hipStream_t s);
+  ~UmprProfScope();
+  int idx; hipStream_t stream;
+};

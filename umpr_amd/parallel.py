@@ -1,0 +1,61 @@
+"""Data parallelism: one process per GPU, gradients summed with RCCL all-reduce over xGMI.
+
+The reference's only multi-GPU mechanism is single-process ``nn.DataParallel`` (main.py:81-82): inputs are chunked
+on dim 0, every replica runs the full model on its shard, replica losses are averaged (main.py:34) and gradients are
+reduce-added to device 0 - i.e. gradient = mean over replicas of per-shard gradients.  The MI355X-native equivalent
+keeps persistent replicas (no per-step parameter broadcast) and all-reduces the flat gradient arenas
+(umpr_amd/optim.py); the 1/world scaling is folded into the Adam kernel's ``grad_scale``.
+
+xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): few, large collectives are what it wants, so the
+554 MB weight-gradient arena is reduced in `n_buckets` chunks issued on a side stream so that they can overlap.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and join the process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_batch(batch, rank, world):
+    """Contiguous chunks along dim 0, as DataParallel's scatter does (torch.chunk semantics)."""
+    B = batch[0].shape[0]
+    per = -(-B // world)
+    sl = slice(rank * per, min(B, (rank + 1) * per))
+    return tuple(t[sl] if (t.dim() > 0 and t.shape[0] == B) else t for t in batch)
+
+
+def allreduce_arenas(arenas, n_buckets=4):
+    """Sum the flat gradient arenas over all ranks (in place).  Returns after the collectives are enqueued on the
+    current stream (RCCL orders them with the following Adam kernel)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for a in arenas:
+        if a.numel() > (1 << 22) and n_buckets > 1:
+            for chunk in torch.chunk(a, n_buckets):
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(a, op=dist.ReduceOp.SUM)
+
+
+def allreduce_scalars(values, device):
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
