@@ -48,6 +48,22 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU share of this process: scheduler affinity capped by the cgroup quota (os.cpu_count() reports the whole host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def note(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def to_device(batch, dev):
     u, i, ui, ul, il, uil, photos, labels = batch
     # lengths stay on the host, like the reference (src/model.py:18)
@@ -57,8 +73,9 @@ def to_device(batch, dev):
 def cpu_baseline(args, P, rank):
     from oracle import umpr_ref as R  # the checker, timed as the CPU baseline ("port")
     from umpr_amd.synthetic import make_batch
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    note(f"cpu baseline on {cores} host threads")
     Pc = {k: v.clone() for k, v in P.items()}
     for k, p in Pc.items():
         if k != "embedding.weight":
@@ -93,6 +110,7 @@ def main():
     from umpr_amd.synthetic import make_batch, make_param_state
     from umpr_amd.train import train_step
 
+    torch.set_num_threads(host_cores())
     rank, local, world = parallel.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
@@ -117,9 +135,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    note("model and batch resident; warm-up")
     for _ in range(args.warmup):
         train_step(model, opt, batch, world)
     barrier()
+    note("timed region")
     L.fn["umpr_profile_reset"]()
     L.fn["umpr_profile_enable"](1)
     t0 = time.perf_counter()
@@ -129,6 +149,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.fn["umpr_profile_enable"](0)
+    note(f"{args.steps} steps in {dt:.3f} s")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

