@@ -111,6 +111,7 @@ def main():
     from umpr_amd.train import train_step
 
     torch.set_num_threads(host_cores())
+    torch.manual_seed(0)  # dropout masks derive from torch.initial_seed()
     rank, local, world = parallel.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"

@@ -133,9 +133,11 @@ int umpr_vgg16_bwd(const float* images, const float* const* params, int n_img, i
                    const uint8_t* masks, const float* d_out, float* const* grads, float* ws, size_t ws_bytes,
                    void* stream);
 /* per-layer entry points (also what the composite calls) */
+/* wpack / wt: scratch of umpr_conv3x3_pack_bytes(Cin, Cout) - the kernels read the weights in a packed order */
+size_t umpr_conv3x3_pack_bytes(int Cin, int Cout);
 int umpr_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
-                     int Cout, int relu, void* stream);
-/* dx = conv_transpose(dy, w) [* (mask_src > 0)]; wt: scratch [Cin][Cout*9] */
+                     int Cout, int relu, float* wpack, void* stream);
+/* dx = conv_transpose(dy, w) [* (mask_src > 0)] */
 int umpr_conv3x3_bwd_data(const float* dy, const float* w, const float* mask_src /*or NULL*/, float* dx, int N,
                           int Cin, int H, int W, int Cout, float* wt, void* stream);
 size_t umpr_conv3x3_bwd_weight_ws_bytes(int N, int Cin, int Cout, int H, int W);

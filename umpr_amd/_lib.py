@@ -47,7 +47,8 @@ SIGNATURES = {
     "umpr_vgg16_ws_bytes": ("i", "z"),
     "umpr_vgg16_fwd": ("ppiiiuppppzp", "i"),
     "umpr_vgg16_bwd": ("ppiipppppzp", "i"),
-    "umpr_conv3x3_fwd": ("ppppiiiiiip", "i"),
+    "umpr_conv3x3_pack_bytes": ("ii", "z"),
+    "umpr_conv3x3_fwd": ("ppppiiiiiipp", "i"),
     "umpr_conv3x3_bwd_data": ("ppppiiiiipp", "i"),
     "umpr_conv3x3_bwd_weight_ws_bytes": ("iiiii", "z"),
     "umpr_conv3x3_bwd_weight": ("ppppiiiiipzp", "i"),

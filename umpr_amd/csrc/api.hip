@@ -274,7 +274,7 @@ size_t vgg_scratch_bytes(int n) {
   fcs *= sizeof(float);
   return align_up(slab > fcs ? slab : fcs, 256);
 }
-constexpr size_t kWtFloats = (size_t)512 * 512 * 9;
+constexpr size_t kWtFloats = (size_t)512 * 512 * 9 + 4096;  // >= umpr_conv3x3_pack_floats of every VGG layer
 }  // namespace
 
 size_t umpr_vgg16_fwd_ws_bytes(int n_img) { return vgg_scratch_bytes(n_img); }
@@ -285,14 +285,14 @@ size_t umpr_vgg16_ws_bytes(int n_img) {
   return (2 * big + kWtFloats) * sizeof(float) + vgg_scratch_bytes(n_img);
 }
 
+size_t umpr_conv3x3_pack_bytes(int Cin, int Cout) { return umpr_conv3x3_pack_floats(Cin, Cout) * sizeof(float); }
 int umpr_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H_, int W,
-                     int Cout, int relu, void* stream) {
-  return umpr_conv3x3_igemm(x, w, bias, nullptr, y, N, Cin, H_, W, Cout, relu, S(stream));
+                     int Cout, int relu, float* wpack, void* stream) {
+  return umpr_conv3x3_run(x, w, 0, bias, nullptr, y, N, Cin, Cout, H_, W, relu, wpack, S(stream));
 }
 int umpr_conv3x3_bwd_data(const float* dy, const float* w, const float* mask_src, float* dx, int N, int Cin, int H_,
                           int W, int Cout, float* wt, void* stream) {
-  if (int rc = umpr_conv3x3_flip_transpose(w, wt, Cout, Cin, S(stream))) return rc;
-  return umpr_conv3x3_igemm(dy, wt, nullptr, mask_src, dx, N, Cout, H_, W, Cin, 0, S(stream));
+  return umpr_conv3x3_run(dy, w, 1, nullptr, mask_src, dx, N, Cin, Cout, H_, W, 0, wt, S(stream));
 }
 size_t umpr_conv3x3_bwd_weight_ws_bytes(int N, int Cin, int Cout, int H_, int W) {
   return umpr_conv3x3_wgrad_ws_bytes(N, Cin, Cout, H_, W);
@@ -320,8 +320,8 @@ int umpr_vgg16_fwd(const float* images, const float* const* params, int n, int t
     for (int j = 0; j < kConvPerBlock[b]; ++j, ++ci) {
       float* y = acts + L.conv_off[ci];
       const int hw = L.conv_hw[ci];
-      if (int rc = umpr_conv3x3_igemm(x, params[2 * ci], params[2 * ci + 1], nullptr, y, n, L.conv_cin[ci], hw, hw,
-                                      L.conv_cout[ci], 1, s)) return rc;
+      if (int rc = umpr_conv3x3_run(x, params[2 * ci], 0, params[2 * ci + 1], nullptr, y, n, L.conv_cin[ci],
+                                    L.conv_cout[ci], hw, hw, 1, ws, s)) return rc;
       x = y;
     }
     const int hw = L.conv_hw[ci - 1];
@@ -398,10 +398,9 @@ int umpr_vgg16_bwd(const float* images, const float* const* params, int n, int t
       if (int rc = umpr_conv3x3_wgrad(g, xin, grads[2 * ci], grads[2 * ci + 1], n, cin, cout, hw, hw, 0, scratch,
                                       slab_bytes, s)) return rc;
       if (ci == 0) break;
-      if (int rc = umpr_conv3x3_flip_transpose(params[2 * ci], wt, cout, cin, s)) return rc;
       // input came straight from a conv+ReLU (j > 0): mask by it; from a pool (j == 0): the pool backward masks
       const float* mask = j > 0 ? xin : nullptr;
-      if (int rc = umpr_conv3x3_igemm(g, wt, nullptr, mask, cur, n, cout, hw, hw, cin, 0, s)) return rc;
+      if (int rc = umpr_conv3x3_run(g, params[2 * ci], 1, nullptr, mask, cur, n, cin, cout, hw, hw, 0, wt, s)) return rc;
       g = cur; { float* t = cur; cur = oth; oth = t; }
     }
     if (ci == 0 && b == 0) break;

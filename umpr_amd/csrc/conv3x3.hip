@@ -11,6 +11,7 @@
 #include "umpr_common.h"
 #include "umpr_internal.h"
 #include "umpr_tiles.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -74,19 +75,21 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvParams p) {
 
   LA ra;
   float rb[NPASS];
+  unsigned rbok = 0;
   auto load_b = [&](int k0) {
+    rbok = 0;
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
       const int k = k0 + j * KROWS + krow;
       const int c = k / 9, t = k - c * 9;
-      float v = 0.f;
-      if (k < K && ((tapmask >> t) & 1)) v = p.x[xbase + (long)c * HW + (t / 3 - 1) * p.W + (t % 3 - 1)];
-      rb[j] = v;
+      const bool ok = k < K && ((tapmask >> t) & 1);
+      rb[j] = p.x[ok ? xbase + (long)c * HW + (t / 3 - 1) * p.W + (t % 3 - 1) : 0];  // branch-free, select at store
+      rbok |= (unsigned)ok << j;
     }
   };
   auto store_b = [&](float* S) {
 #pragma unroll
-    for (int j = 0; j < NPASS; ++j) S[(j * KROWS + krow) * LDB + pl] = rb[j];
+    for (int j = 0; j < NPASS; ++j) S[(j * KROWS + krow) * LDB + pl] = ((rbok >> j) & 1) ? rb[j] : 0.f;
   };
 
   const int nt = (K + BK - 1) / BK;
@@ -96,7 +99,18 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvParams p) {
   store_b(Bs[0]);
   __syncthreads();
   const int l31 = lane & 31, kh = lane >> 5;
-  for (int t = 0; t < nt; ++t) {
+  // outer loop = one MFMA accumulation chain (KFLUSH stages): inside it the accumulators are written only by
+  // MFMAs and stay in AGPRs (a conditional fold inside the stage loop made hipcc move all of them through VGPRs
+  // every stage: 128 v_accvgpr moves + an MFMA pipeline drain per stage)
+  for (int t0 = 0; t0 < nt; t0 += KFLUSH) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int t1 = min(nt, t0 + KFLUSH);
+  for (int t = t0; t < t1; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt) {
       ra.load(p.wm, K, nullptr, m0, p.Cout, (t + 1) * BK, K, vecA, tid);
@@ -104,33 +118,37 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvParams p) {
     }
     const float* as = As[cur] + wm * WTM + l31;
     const float* bs = Bs[cur] + wn * WTN + l31;
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = as[kh * LDA + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = bs[kh * LDB + j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + kh) * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) a[nb][i] = as[(2 * (kk + 1) + kh) * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + kh) * LDB + j * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-    }
-    if (((t + 1) & (KFLUSH - 1)) == 0 || t + 1 == nt) {
+        for (int j = 0; j < TN; ++j) b[nb][j] = bs[(2 * (kk + 1) + kh) * LDB + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          tot[i][j] += acc[i][j];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[cb][i], b[cb][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 1 < nt) {
       ra.store(As[cur ^ 1], tid);
       store_b(Bs[cur ^ 1]);
     }
     __syncthreads();
+  }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
   }
 
 #pragma unroll
@@ -154,6 +172,247 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvParams p) {
         }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// v2 of the implicit GEMM for the VGG map widths (W = H in {224,112,56,28,14}): instead of gathering an im2col
+// tile element by element, each k-stage copies the raw input rows of CC = 4 channels that the 128-pixel tile
+// touches (plus a one-pixel halo) into LDS with float4 loads, and the nine taps are formed when the MFMA-B
+// fragment is read: lane address = per-lane pixel base + an immediate.  The inner loop has no VALU work at all
+// (v1 spent 14 VALU instructions per MFMA on index arithmetic - rocprofv3 SQ_INSTS_VALU).
+//  * "virtual rows": image n, row y lives at v = n*(H+2) + y + 1, so rows above/below an image are zero rows and a
+//    tile of consecutive flat pixels may straddle two images.
+//  * weights arrive PACKED (pack_weights_kernel): wp[m][stage][k'] with k' = 2*(c_lo*9 + tap) + half and channel
+//    = 4*stage + c_lo + 2*half, zero-padded to whole stages.  The two k of one MFMA step then differ by a constant
+//    LDS offset in the patch (2 planes), which goes into the per-lane base of the upper half-wave, and the weight
+//    tile is staged with aligned float4 loads and compile-time LDS offsets.
+//  * every global load is unconditional (clamped address; validity applied when the registers go to LDS) and the
+//    stage body is branch-free; 2 waves/SIMD (launch bounds) let one workgroup's staging overlap the other's MFMAs.
+constexpr int V2_CC = 4, V2_KC = V2_CC * 9;
+
+template <int BM, int W, int PR>
+__global__ __launch_bounds__(256, 2) void conv3x3_igemm_v2_kernel(ConvParams p) {
+  constexpr int BN = 128, CC = V2_CC, KC = V2_KC;
+  constexpr int RW = W + 2, PLANE = PR * RW;
+  constexpr int LDA = BM + 2;
+  constexpr int VEC = (W % 4 == 0) ? 4 : 2;
+  constexpr int WV = W / VEC;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AU = BM * 9;                 // float4 units of one weight stage
+  constexpr int AV = (AU + 255) / 256;
+  constexpr int BU = CC * PR * WV;           // vector units of one patch stage
+  constexpr int BV = (BU + 255) / 256;
+  constexpr int SFLUSH = 4;                  // stages per MFMA accumulation chain (144 k)
+  __shared__ __attribute__((aligned(16))) float As[2][KC * LDA];
+  __shared__ __attribute__((aligned(16))) float Ps[2][CC * PLANE];
+  __shared__ long rowsrc[PR];                // element offset of (n_r, c=0, yy, 0) or -1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int H = p.H, HW = H * W, HP = H + 2;
+  const long NP = (long)p.N * HW;
+  const long p0 = (long)blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const int ns = (p.C + CC - 1) / CC;
+  const int Kp = ns * KC;
+  const int n0 = (int)(p0 / HW);
+  const int y0 = (int)(p0 % HW) / W;
+  const long v_first = (long)n0 * HP + y0 + 1;
+
+  if (tid < PR) {
+    const long v = v_first - 1 + tid;
+    const int nr = (int)(v / HP);
+    const int yy = (int)(v - (long)nr * HP) - 1;
+    rowsrc[tid] = (v >= 0 && nr < p.N && yy >= 0 && yy < H) ? ((long)nr * p.C * H + yy) * W : -1;
+  }
+  for (int e = tid; e < 2 * CC * PLANE; e += 256) (&Ps[0][0])[e] = 0.f;  // halo columns stay zero for good
+  __syncthreads();
+
+  // per-lane B base offsets (floats) for the TN column tiles
+  int boff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    long pq = p0 + wn * WTN + j * 32 + l31;
+    if (pq >= NP) pq = NP - 1;
+    const int n = (int)(pq / HW), yx = (int)(pq % HW);
+    const int y = yx / W, x = yx - y * W;
+    const long v = (long)n * HP + y + 1;
+    boff[j] = (int)(v - v_first) * RW + x + half * 2 * PLANE;
+  }
+  // per-thread staging geometry (stage independent)
+  const float* asrc[AV];
+  int adst[AV];
+#pragma unroll
+  for (int v = 0; v < AV; ++v) {
+    int u = tid + v * 256;
+    if (u >= AU) u = AU - 1;                 // surplus lanes of the last pass repeat the last unit (identical stores)
+    const int row = u / 9, q = u - row * 9;
+    const int mr = min(m0 + row, p.Cout - 1);  // rows past Cout read row Cout-1; their outputs are never written
+    asrc[v] = p.wm + (long)mr * Kp + 4 * q;
+    adst[v] = 4 * q * LDA + row;
+  }
+  long bsrc[BV];
+  int bdst[BV], bch[BV];
+#pragma unroll
+  for (int v = 0; v < BV; ++v) {
+    int u = tid + v * 256;
+    if (u >= BU) u = BU - 1;
+    const int c = u / (PR * WV), rq = u - c * (PR * WV);
+    const int r = rq / WV, q = rq - r * WV;
+    const long rs = rowsrc[r];
+    bsrc[v] = rs >= 0 ? rs + (long)c * HW + q * VEC : -1;
+    bdst[v] = c * PLANE + r * RW + 1 + q * VEC;
+    bch[v] = c;
+  }
+
+  f32x16 acc[TM][TN], tot[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+  float4 ra[AV];
+  float4 rb[BV];
+  unsigned okb = 0;
+  auto load = [&](int s) {
+    okb = 0;
+#pragma unroll
+    for (int v = 0; v < AV; ++v) ra[v] = *reinterpret_cast<const float4*>(asrc[v] + s * KC);
+#pragma unroll
+    for (int v = 0; v < BV; ++v) {
+      const bool ok = bsrc[v] >= 0 && s * CC + bch[v] < p.C;
+      const float* src = p.x + (ok ? bsrc[v] + (long)s * CC * HW : 0);
+      if (VEC == 4) {
+        rb[v] = *reinterpret_cast<const float4*>(src);
+      } else {
+        const float2 t2 = *reinterpret_cast<const float2*>(src);
+        rb[v] = make_float4(t2.x, t2.y, 0.f, 0.f);
+      }
+      okb |= (unsigned)ok << v;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < AV; ++v) {
+      float* S = As[buf] + adst[v];
+      S[0] = ra[v].x; S[LDA] = ra[v].y; S[2 * LDA] = ra[v].z; S[3 * LDA] = ra[v].w;
+    }
+#pragma unroll
+    for (int v = 0; v < BV; ++v) {
+      const bool ok = (okb >> v) & 1;
+      float* S = Ps[buf] + bdst[v];
+      S[0] = ok ? rb[v].x : 0.f; S[1] = ok ? rb[v].y : 0.f;
+      if (VEC == 4) { S[2] = ok ? rb[v].z : 0.f; S[3] = ok ? rb[v].w : 0.f; }
+    }
+  };
+
+  load(0);
+  store(0);
+  __syncthreads();
+  // outer loop = one MFMA accumulation chain (SFLUSH stages): inside it the accumulators are written only by MFMAs
+  // and stay in AGPRs (a conditional fold inside the stage loop made hipcc move all of them through VGPRs per stage)
+  for (int s0 = 0; s0 < ns; s0 += SFLUSH) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int s1 = min(ns, s0 + SFLUSH);
+    for (int s = s0; s < s1; ++s) {
+      const int cur = s & 1;
+      load(min(s + 1, ns - 1));              // the last stage re-loads itself: keeps the body branch-free
+      const float* as = As[cur] + half * LDA + wm * WTM + l31;
+      const float* ps = Ps[cur];
+      // software-pipelined fragment reads: the LDS reads of step kk+1 are in flight while the MFMAs of step kk run
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = ps[boff[j]];
+#pragma unroll
+      for (int kk = 0; kk < KC / 2; ++kk) {
+        const int cb = kk & 1, nb = cb ^ 1;
+        if (kk + 1 < KC / 2) {
+          const int k1 = kk + 1, cl = k1 / 9, tap = k1 % 9;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[nb][i] = as[2 * k1 * LDA + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[nb][j] = ps[boff[j] + cl * PLANE + (tap / 3) * RW + (tap % 3)];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this step's MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[cb][i], b[cb][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      store(cur ^ 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long pq = p0 + wn * WTN + j * 32 + l31;
+    if (pq >= NP) continue;
+    const int n = (int)(pq / HW), yx = (int)(pq % HW);
+    const long obase = (long)n * p.Cout * HW + yx;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * WTM + i * 32 + mfma_row(r, lane);
+        if (co < p.Cout) {
+          float v = tot[i][j][r];
+          if (p.bias) v += p.bias[co];
+          if (p.relu) v = fmaxf(v, 0.f);
+          const long o = obase + (long)co * HW;
+          if (p.mask) v = p.mask[o] > 0.f ? v : 0.f;
+          p.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// wp[m][stage][k'] from w [Cout][Cin][3][3].  transposed = 0: m = cout, reduction channel c = cin, tap as is;
+// transposed = 1 (data gradient): m = cin, c = cout, tap flipped (8 - tap).  Channels past C are zero.
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, int C, int CinW,
+                                    int transposed) {
+  const int ns = (C + V2_CC - 1) / V2_CC;
+  const long total = (long)M * ns * V2_KC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int kq = (int)(i % V2_KC);
+    const long r = i / V2_KC;
+    const int s = (int)(r % ns), m = (int)(r / ns);
+    const int hf = kq & 1, j = kq >> 1;
+    const int cl = j / 9, tap = j - cl * 9;
+    const int c = s * V2_CC + cl + 2 * hf;
+    float v = 0.f;
+    if (c < C) v = transposed ? w[((long)c * CinW + m) * 9 + 8 - tap] : w[((long)m * CinW + c) * 9 + tap];
+    wp[i] = v;
+  }
+}
+
+template <int W, int PR>
+void launch_v2(const ConvParams& p, hipStream_t s) {
+  const long NP = (long)p.N * p.H * p.W;
+  if (p.Cout <= 64) {
+    dim3 grid(cdiv(NP, 128), cdiv(p.Cout, 64));
+    conv3x3_igemm_v2_kernel<64, W, PR><<<grid, 256, 0, s>>>(p);
+  } else {
+    dim3 grid(cdiv(NP, 128), cdiv(p.Cout, 128));
+    conv3x3_igemm_v2_kernel<128, W, PR><<<grid, 256, 0, s>>>(p);
   }
 }
 
@@ -214,8 +473,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradParams p) {
   constexpr int XV = (64 * 102 + 255) / 256;  // 26 loads cover the largest patch
   float rg[8];
   float rx[XV];
+  unsigned okg = 0, okx = 0;  // validity bits, applied when the registers are written to LDS
 
   auto load = [&](int seg) {
+    okg = 0; okx = 0;
     const int sx = seg % p.segs_x;
     const int sy = (seg / p.segs_x) % p.segs_y;
     const int n = seg / (p.segs_x * p.segs_y);
@@ -225,38 +486,35 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradParams p) {
       const int e = tid + v * 256;
       const int co = e >> 5, px = e & 31;
       const int r = px / p.CW, c = px - r * p.CW;
-      float val = 0.f;
-      if (px < npx && co0 + co < p.Cout && y0 + r < p.H && x0 + c < p.W)
-        val = p.gz[((long)n * p.Cout + co0 + co) * HW + (y0 + r) * p.W + x0 + c];
-      rg[v] = val;
+      const bool ok = px < npx && co0 + co < p.Cout && y0 + r < p.H && x0 + c < p.W;
+      rg[v] = p.gz[ok ? ((long)n * p.Cout + co0 + co) * HW + (y0 + r) * p.W + x0 + c : 0];  // branch-free
+      okg |= (unsigned)ok << v;
     }
 #pragma unroll
     for (int v = 0; v < XV; ++v) {
       const int e = tid + v * 256;
-      float val = 0.f;
-      if (e < xs_total) {
-        const int ci = e / patch, q = e - ci * patch;
-        const int rr = q / RW, cc = q - rr * RW;
-        const int yy = y0 - 1 + rr, xx = x0 - 1 + cc;
-        if (ci0 + ci < p.Cin && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
-          val = p.x[((long)n * p.Cin + ci0 + ci) * HW + yy * p.W + xx];
-      }
-      rx[v] = val;
+      const int ci = e / patch, q = e - ci * patch;
+      const int rr = q / RW, cc = q - rr * RW;
+      const int yy = y0 - 1 + rr, xx = x0 - 1 + cc;
+      const bool ok = e < xs_total && ci0 + ci < p.Cin && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      rx[v] = p.x[ok ? ((long)n * p.Cin + ci0 + ci) * HW + yy * p.W + xx : 0];  // branch-free
+      okx |= (unsigned)ok << v;
     }
   };
   auto store = [&](int buf) {
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
       const int e = tid + v * 256;
-      Gs[buf][(e >> 5) * WG_LDG + (e & 31)] = rg[v];
-      if (p.bslab && blockIdx.x == 0) bsum[v] += rg[v];
+      const float gv = ((okg >> v) & 1) ? rg[v] : 0.f;
+      Gs[buf][(e >> 5) * WG_LDG + (e & 31)] = gv;
+      if (p.bslab && blockIdx.x == 0) bsum[v] += gv;
     }
 #pragma unroll
     for (int v = 0; v < XV; ++v) {
       const int e = tid + v * 256;
       if (e < xs_total) {
         const int ci = e / patch, q = e - ci * patch;
-        Xs[buf][ci * PL + q] = rx[v];
+        Xs[buf][ci * PL + q] = ((okx >> v) & 1) ? rx[v] : 0.f;
       }
     }
   };
@@ -271,16 +529,28 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradParams p) {
     if (s + 1 < send) load(s + 1);
     const float* gs = Gs[cur] + (wm * 32 + l31) * WG_LDG;
     const float* xs = Xs[cur] + (wn * 32 + l31) * PL;
-#pragma unroll 4
-    for (int kk = 0; kk < 16; ++kk) {
-      const int px = 2 * kk + kh;
-      const float a = gs[px];
-      const float* xp = xs + pxoff[px];
+    // fragment reads of pixel pair kk+1 are issued before the nine MFMAs of pair kk
+    float a[2], b[2][9];
+    {
+      a[0] = gs[kh];
+      const float* xp = xs + pxoff[kh];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float b = xp[(t / 3) * RW + (t % 3)];
-        acc[t] = mfma32(a, b, acc[t]);
+      for (int t = 0; t < 9; ++t) b[0][t] = xp[(t / 3) * RW + (t % 3)];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk + 1 < 16) {
+        const int px = 2 * (kk + 1) + kh;
+        a[nb] = gs[px];
+        const float* xp = xs + pxoff[px];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[nb][t] = xp[(t / 3) * RW + (t % 3)];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = mfma32(a[cb], b[cb][t], acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (s + 1 < send) store(cur ^ 1);
     __syncthreads();
@@ -305,6 +575,151 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradParams p) {
       for (int o = 16; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
       const int co = co0 + (tid >> 5) + 8 * v;
       if ((tid & 31) == 0 && co < p.Cout) p.bslab[(long)split * p.Cout + co] = sv;
+    }
+  }
+}
+
+// wgrad v2: the same tiling with the segment geometry (R rows x CW columns, R*CW <= 32, CW even) as template
+// parameters.  What changed against the generic kernel above, and why (rocprofv3: 7.8 VALU instructions per MFMA and
+// 1 wave/SIMD left the MFMA pipe 57% idle):
+//  * staging is "position owned": a thread owns one position of the (R+2)x(CW+2) halo patch (or one pixel of the gz
+//    tile) and walks over channels, so an address is one add and the validity test is done once per segment;
+//  * all loads are unconditional (clamped address) and the zero-select happens when the registers go to LDS;
+//  * fragment addresses are per-lane base + immediate (pixel pairs never straddle a patch row because CW is even);
+//  * launch bounds of 2 waves/SIMD: a second workgroup's MFMAs cover this one's staging.
+template <int R, int CW>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_v2_kernel(WgradParams p) {
+  constexpr int RW = CW + 2, PP = (R + 2) * RW, PL = PP | 1, NPX = R * CW;
+  constexpr int G = 256 / PP;                 // channel groups staged in parallel
+  constexpr int CPG = (64 + G - 1) / G;       // channels per group = loads per thread
+  static_assert((CW & 1) == 0 && NPX <= 32 && PP <= 102, "segment geometry");
+  __shared__ float Gs[2][64 * WG_LDG];
+  __shared__ float Xs[2][64 * PL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+  const int split = blockIdx.z;
+  const int H = p.H, W = p.W, HW = H * W;
+
+  // staging geometry of this thread
+  const int pg = tid / PP, pos = tid - pg * PP;
+  const bool pact = pg < G;
+  const int prr = pos / RW, pcc = pos - prr * RW;
+  const int gpx = tid & 31, gco = tid >> 5;
+  const int gr = gpx / CW, gc = gpx - gr * CW;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) bsum[v] = 0.f;
+
+  const int sbeg = split * p.segs_per_split;
+  const int send = min(p.nsegs, sbeg + p.segs_per_split);
+  float rg[8];
+  float rx[CPG];
+  unsigned okg = 0, okx = 0;
+
+  auto load = [&](int seg) {
+    const int sx = seg % p.segs_x;
+    const int sy = (seg / p.segs_x) % p.segs_y;
+    const int n = seg / (p.segs_x * p.segs_y);
+    const int y0 = sy * R, x0 = sx * CW;
+    okg = 0; okx = 0;
+    {
+      const bool ok = gpx < NPX && y0 + gr < H && x0 + gc < W;
+      const long base = (((long)n * p.Cout + co0 + gco) * H + y0 + gr) * W + x0 + gc;
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const bool okv = ok && co0 + gco + 8 * v < p.Cout;
+        rg[v] = p.gz[okv ? base + (long)v * 8 * HW : 0];
+        okg |= (unsigned)okv << v;
+      }
+    }
+    {
+      const int yy = y0 - 1 + prr, xx = x0 - 1 + pcc;
+      const bool ok = pact && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const long base = (((long)n * p.Cin + ci0 + pg) * H + yy) * W + xx;
+#pragma unroll
+      for (int v = 0; v < CPG; ++v) {
+        const int ci = pg + G * v;
+        const bool okv = ok && ci < 64 && ci0 + ci < p.Cin;
+        rx[v] = p.x[okv ? base + (long)v * G * HW : 0];
+        okx |= (unsigned)okv << v;
+      }
+    }
+  };
+  auto store = [&](int buf, bool fresh) {  // fresh = false for the redundant re-load of the last segment
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const float gv = ((okg >> v) & 1) ? rg[v] : 0.f;
+      Gs[buf][(gco + 8 * v) * WG_LDG + gpx] = gv;
+      bsum[v] += fresh ? gv : 0.f;
+    }
+    if (pact) {
+#pragma unroll
+      for (int v = 0; v < CPG; ++v) {
+        const int ci = pg + G * v;
+        if (ci < 64) Xs[buf][ci * PL + pos] = ((okx >> v) & 1) ? rx[v] : 0.f;
+      }
+    }
+  };
+
+  if (sbeg < send) {
+    load(sbeg);
+    store(0, true);
+  }
+  __syncthreads();
+  for (int s = sbeg; s < send; ++s) {
+    const int cur = (s - sbeg) & 1;
+    load(min(s + 1, send - 1));
+    const float* gs = Gs[cur] + (wm * 32 + l31) * WG_LDG + kh;
+    const float* xs = Xs[cur] + (wn * 32 + l31) * PL + kh;
+    float a[2], b[2][9];
+    a[0] = gs[0];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) b[0][t] = xs[(t / 3) * RW + (t % 3)];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk + 1 < 16) {
+        constexpr int dummy = 0; (void)dummy;
+        const int px = 2 * (kk + 1);              // even pixel of the pair; the odd one is +1 (CW even)
+        const int po = (px / CW) * RW + (px % CW);
+        a[nb] = gs[px];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[nb][t] = xs[po + (t / 3) * RW + (t % 3)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = mfma32(a[cb], b[cb][t], acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    store(cur ^ 1, s + 1 < send);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + mfma_row(r, lane);
+      const int ci = ci0 + wn * 32 + l31;
+      if (co < p.Cout && ci < p.Cin) p.slab[(((long)split * 9 + t) * p.Cout + co) * p.Cin + ci] = acc[t][r];
+    }
+  }
+  if (p.bslab && blockIdx.x == 0) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      float sv = bsum[v];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+      const int co = co0 + gco + 8 * v;
+      if (gpx == 0 && co < p.Cout) p.bslab[(long)split * p.Cout + co] = sv;
     }
   }
 }
@@ -385,17 +800,55 @@ __global__ void maxpool2_bwd_relu_kernel(const float* __restrict__ x, const floa
 }  // namespace
 
 // ---- internal host entry points ------------------------------------------------------------------------------
-int umpr_conv3x3_igemm(const float* x, const float* wm, const float* bias, const float* mask, float* y, int N, int C,
-                       int H, int W, int Cout, int relu, hipStream_t s) {
-  UMPR_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3: bad shape");
-  ConvParams p{x, wm, bias, mask, y, N, C, H, W, Cout, relu};
+static bool g_conv_force_v1 = false;  // UMPR_CONV_V1=1 selects the generic gather kernel (A/B runs)
+static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; } } g_conv_env_init;
+size_t umpr_conv3x3_pack_floats(int Cin, int Cout) {
+  const size_t a = (size_t)Cout * ((Cin + V2_CC - 1) / V2_CC) * V2_KC;   // forward pack
+  const size_t b = (size_t)Cin * ((Cout + V2_CC - 1) / V2_CC) * V2_KC;   // transposed pack
+  const size_t c = (size_t)Cin * Cout * 9;                               // plain flip-transpose (generic kernel)
+  size_t m = a > b ? a : b;
+  return m > c ? m : c;
+}
+
+// Forward (transposed = 0):  y[N][Cout] = relu?(conv(x[N][Cin], w) + bias)
+// Data gradient (transposed = 1):  y[N][Cin] = conv^T(x[N][Cout], w) * [mask > 0]
+// w is always the parameter [Cout][Cin][3][3]; wpack: scratch of umpr_conv3x3_pack_floats(Cin, Cout) floats.
+int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
+                     int N, int Cin, int Cout, int H, int W, int relu, float* wpack, hipStream_t s) {
+  UMPR_REQUIRE(N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3: bad shape");
+  const int M = transposed ? Cin : Cout;   // output channels of this launch
+  const int C = transposed ? Cout : Cin;   // reduction channels
   const long NP = (long)N * H * W;
-  UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * Cout * C * 9, s);
-  if (Cout <= 64) {
-    dim3 grid(cdiv(NP, 128), cdiv(Cout, 64));
+  const bool v2 = H == W && !g_conv_force_v1 && wpack && (W == 224 || W == 112 || W == 56 || W == 28 || W == 14);
+  if (v2) {
+    const long total = (long)M * ((C + V2_CC - 1) / V2_CC) * V2_KC;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    pack_weights_kernel<<<blocks, 256, 0, s>>>(w, wpack, M, C, Cin, transposed);
+    UMPR_LAUNCH_CHECK("pack_weights");
+    ConvParams p{x, wpack, bias, mask, y, N, C, H, W, M, relu};
+    UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
+    if (W == 224) launch_v2<224, 4>(p, s);
+    else if (W == 112) launch_v2<112, 5>(p, s);
+    else if (W == 56) launch_v2<56, 8>(p, s);
+    else if (W == 28) launch_v2<28, 10>(p, s);
+    else launch_v2<14, 15>(p, s);
+    UMPR_LAUNCH_CHECK("conv3x3_igemm_v2");
+    return 0;
+  }
+  const float* wm = w;
+  if (transposed) {
+    UMPR_REQUIRE(wpack != nullptr, "conv3x3: data gradient needs the weight scratch");
+    if (int rc = umpr_conv3x3_flip_transpose(w, wpack, Cout, Cin, s)) return rc;
+    wm = wpack;
+  }
+  ConvParams p{x, wm, bias, mask, y, N, C, H, W, M, relu};
+  UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
+  if (M <= 64) {
+    dim3 grid(cdiv(NP, 128), cdiv(M, 64));
     conv3x3_igemm_kernel<64, 128><<<grid, 256, 0, s>>>(p);
   } else {
-    dim3 grid(cdiv(NP, 128), cdiv(Cout, 128));
+    dim3 grid(cdiv(NP, 128), cdiv(M, 128));
     conv3x3_igemm_kernel<128, 128><<<grid, 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("conv3x3_igemm");
@@ -411,9 +864,18 @@ int umpr_conv3x3_flip_transpose(const float* w, float* wt, int Cout, int Cin, hi
   return 0;
 }
 
+// pixel segment = R rows x CW columns with R*CW <= 32: full MFMA k-utilisation when W is a multiple of 32/16/8
+static void wgrad_geometry(int W, int* R, int* CW) {
+  if (W % 32 == 0) { *R = 1; *CW = 32; }
+  else if (W % 16 == 0) { *R = 2; *CW = 16; }
+  else if (W % 8 == 0) { *R = 4; *CW = 8; }
+  else if (W < 32) { *R = 32 / W; *CW = W; }
+  else { *R = 1; *CW = 32; }
+}
+
 size_t umpr_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
-  const int CW = W >= 32 ? 32 : W;
-  const int R = W >= 32 ? 1 : (32 / W);
+  int R, CW;
+  wgrad_geometry(W, &R, &CW);
   const int nsegs = N * cdiv(H, R) * cdiv(W, CW);
   const int tiles = cdiv(Cout, 64) * cdiv(Cin, 64);
   int splits = cdiv(1024, tiles);
@@ -425,8 +887,7 @@ int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, in
                        int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
   WgradParams p;
   p.gz = gz; p.x = x; p.N = N; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
-  p.CW = W >= 32 ? 32 : W;
-  p.R = W >= 32 ? 1 : (32 / W);
+  wgrad_geometry(W, &p.R, &p.CW);
   UMPR_REQUIRE(p.R * p.CW <= 32 && (p.R + 2) * (p.CW + 2) <= 102, "wgrad: unsupported width %d", W);
   p.segs_y = cdiv(H, p.R);
   p.segs_x = cdiv(W, p.CW);
@@ -444,7 +905,13 @@ int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, in
   dim3 grid(cdiv(Cin, 64), cdiv(Cout, 64), splits);
   {
     UmprProfScope prof(UMPR_K_CONV_WGRAD, 2.0 * N * H * W * Cout * Cin * 9, s);
-    conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(p);
+    if (g_conv_force_v1) conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(p);
+    else if (p.R == 1 && p.CW == 32) conv3x3_wgrad_v2_kernel<1, 32><<<grid, 256, 0, s>>>(p);
+    else if (p.R == 2 && p.CW == 16) conv3x3_wgrad_v2_kernel<2, 16><<<grid, 256, 0, s>>>(p);
+    else if (p.R == 4 && p.CW == 8) conv3x3_wgrad_v2_kernel<4, 8><<<grid, 256, 0, s>>>(p);
+    else if (p.R == 1 && p.CW == 28) conv3x3_wgrad_v2_kernel<1, 28><<<grid, 256, 0, s>>>(p);
+    else if (p.R == 2 && p.CW == 14) conv3x3_wgrad_v2_kernel<2, 14><<<grid, 256, 0, s>>>(p);
+    else conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("conv3x3_wgrad");
   const long total = (long)9 * Cout * Cin + (db ? Cout : 0);

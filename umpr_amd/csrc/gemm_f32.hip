@@ -70,7 +70,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   }
   __syncthreads();
   const int l31 = lane & 31, kh = lane >> 5;
-  for (int t = 0; t < nt; ++t) {
+  // outer loop = one MFMA accumulation chain (KFLUSH stages): inside it the accumulators are written only by
+  // MFMAs and stay in AGPRs (a conditional fold inside the stage loop made hipcc move all of them through VGPRs
+  // every stage: 128 v_accvgpr moves + an MFMA pipeline drain per stage)
+  for (int t0 = 0; t0 < nt; t0 += KFLUSH) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int t1 = min(nt, t0 + KFLUSH);
+  for (int t = t0; t < t1; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt) {
       ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg + (t + 1) * BK, kend, p.vecA, tid);
@@ -78,33 +89,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
     const float* as = As[cur] + wm * WTM + l31;
     const float* bs = Bs[cur] + wn * WTN + l31;
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = as[kh * LDA + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = bs[kh * LDB + j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + kh) * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) a[nb][i] = as[(2 * (kk + 1) + kh) * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + kh) * LDB + j * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-    }
-    if (((t + 1) & (KFLUSH - 1)) == 0 || t + 1 == nt) {
+        for (int j = 0; j < TN; ++j) b[nb][j] = bs[(2 * (kk + 1) + kh) * LDB + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          tot[i][j] += acc[i][j];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[cb][i], b[cb][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 1 < nt) {
       ra.store(As[cur ^ 1], tid);
       rb.store(Bs[cur ^ 1], tid);
     }
     __syncthreads();
+  }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
   }
 
   // epilogue
@@ -173,8 +188,9 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   p.gatherA = g.gatherA; p.gatherB = g.gatherB;
   p.bias = g.bias; p.bias_mode = g.bias ? g.bias_mode : 0;
   p.act = g.act; p.accumulate = g.accumulate ? 1 : 0; p.alpha = g.alpha;
-  p.vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
-  p.vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+  // float4 staging needs 16-B aligned rows and a contiguous extent that is a multiple of 4 (no partial vectors)
+  p.vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && (((g.transA ? g.M : g.K) & 3) == 0);
+  p.vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && (((g.transB ? g.K : g.N) & 3) == 0);
   const int BM = g.M <= 64 ? 64 : 128;
   const int BN = g.N <= 64 ? 64 : 128;
   const int tm = cdiv(g.M, BM), tn = cdiv(g.N, BN);

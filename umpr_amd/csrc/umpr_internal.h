@@ -45,8 +45,9 @@ struct UmprHead {
 int umpr_head_launch(const UmprHead& p, int backward, hipStream_t s);
 
 // conv3x3.hip
-int umpr_conv3x3_igemm(const float* x, const float* wm, const float* bias, const float* mask, float* y, int N, int C,
-                       int H, int W, int Cout, int relu, hipStream_t s);
+size_t umpr_conv3x3_pack_floats(int Cin, int Cout);
+int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
+                     int N, int Cin, int Cout, int H, int W, int relu, float* wpack, hipStream_t s);
 int umpr_conv3x3_flip_transpose(const float* w, float* wt, int Cout, int Cin, hipStream_t s);
 size_t umpr_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,

@@ -13,47 +13,45 @@ struct TileRegs {
   static constexpr int LD = KCONTIG ? TILE + 2 : TILE + 4;
   float4 r[NV];
 
+  // Branch-free AND wait-free at load time: every lane always issues its loads (out-of-range lanes read element 0 of
+  // the operand); validity is kept as a bit mask and the zero-select happens in store(), i.e. after the MFMAs of the
+  // current tile.  A per-lane `if (valid) v = load`, or a select right behind the load, makes hipcc wait vmcnt(0)
+  // per load: the loads then complete one L2 round trip after the other (rocprofv3: SQ_WAIT_ANY was 43% of the wave
+  // lifetime).  vec_ok (wave-uniform) promises 16-B alignment and extents that are multiples of 4.
+  unsigned okmask;
   __device__ __forceinline__ void load(const float* __restrict__ base, long ld, const int64_t* __restrict__ gather,
                                        int mn0, int MN, int k0, int kend, int vec_ok, int tid) {
+    okmask = 0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int e = tid + v * 256;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      int o0, o1, o2, o3;
+      const float* p;
       if (KCONTIG) {
         const int mn = e >> 2, kq = e & 3;
         const int gm = mn0 + mn, gk = k0 + 4 * kq;
-        long row = -1;
-        if (gm < MN) row = gather ? (long)gather[gm] : (long)gm;
-        if (row >= 0 && gk < kend) {
-          const float* p = base + row * ld + gk;
-          if (vec_ok && gk + 3 < kend) {
-            val = *reinterpret_cast<const float4*>(p);
-          } else {
-            val.x = p[0];
-            if (gk + 1 < kend) val.y = p[1];
-            if (gk + 2 < kend) val.z = p[2];
-            if (gk + 3 < kend) val.w = p[3];
-          }
-        }
+        long row = gm < MN ? (long)gm : -1;
+        if (gather) row = gather[gm < MN ? gm : 0] | (gm < MN ? 0L : -1L);
+        const bool rv = row >= 0;
+        p = base + (rv ? row * ld + gk : 0);
+        o0 = rv && gk < kend; o1 = rv && gk + 1 < kend; o2 = rv && gk + 2 < kend; o3 = rv && gk + 3 < kend;
       } else {
         constexpr int QPR = TILE / 4;
         const int k = e / QPR, q = e % QPR;
         const int gk = k0 + k, gm = mn0 + 4 * q;
-        long row = -1;
-        if (gk < kend) row = gather ? (long)gather[gk] : (long)gk;
-        if (row >= 0 && gm < MN) {
-          const float* p = base + row * ld + gm;
-          if (vec_ok && gm + 3 < MN) {
-            val = *reinterpret_cast<const float4*>(p);
-          } else {
-            val.x = p[0];
-            if (gm + 1 < MN) val.y = p[1];
-            if (gm + 2 < MN) val.z = p[2];
-            if (gm + 3 < MN) val.w = p[3];
-          }
-        }
+        long row = gk < kend ? (long)gk : -1;
+        if (gather) row = gather[gk < kend ? gk : 0] | (gk < kend ? 0L : -1L);
+        const bool rv = row >= 0;
+        p = base + (rv ? row * ld + gm : 0);
+        o0 = rv && gm < MN; o1 = rv && gm + 1 < MN; o2 = rv && gm + 2 < MN; o3 = rv && gm + 3 < MN;
       }
-      r[v] = val;
+      if (vec_ok) {
+        r[v] = *reinterpret_cast<const float4*>(o0 ? p : base);
+        o1 = o2 = o3 = o0;
+      } else {
+        r[v].x = *(o0 ? p : base); r[v].y = *(o1 ? p + 1 : base); r[v].z = *(o2 ? p + 2 : base); r[v].w = *(o3 ? p + 3 : base);
+      }
+      okmask |= (unsigned)(o0 | (o1 << 1) | (o2 << 2) | (o3 << 3)) << (4 * v);
     }
   }
 
@@ -61,16 +59,18 @@ struct TileRegs {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int e = tid + v * 256;
+      const unsigned m = okmask >> (4 * v);
+      const float4 val = make_float4((m & 1) ? r[v].x : 0.f, (m & 2) ? r[v].y : 0.f, (m & 4) ? r[v].z : 0.f, (m & 8) ? r[v].w : 0.f);
       if (KCONTIG) {
         const int mn = e >> 2, kq = e & 3;
-        S[(4 * kq + 0) * LD + mn] = r[v].x;
-        S[(4 * kq + 1) * LD + mn] = r[v].y;
-        S[(4 * kq + 2) * LD + mn] = r[v].z;
-        S[(4 * kq + 3) * LD + mn] = r[v].w;
+        S[(4 * kq + 0) * LD + mn] = val.x;
+        S[(4 * kq + 1) * LD + mn] = val.y;
+        S[(4 * kq + 2) * LD + mn] = val.z;
+        S[(4 * kq + 3) * LD + mn] = val.w;
       } else {
         constexpr int QPR = TILE / 4;
         const int k = e / QPR, q = e % QPR;
-        *reinterpret_cast<float4*>(&S[k * LD + 4 * q]) = r[v];
+        *reinterpret_cast<float4*>(&S[k * LD + 4 * q]) = val;
       }
     }
   }
