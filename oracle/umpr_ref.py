@@ -191,10 +191,11 @@ def vgg16_forward(images, P, prefix="visual_net.vgg16.0.", train=False,
 # ----------------------------------------------------------------------------------------------
 # VisualNet (src/model.py:212-229)
 # ----------------------------------------------------------------------------------------------
-def visual_net(images, c_u, c_i, P, train=False, dropout_masks=None):
+def visual_net(images, c_u, c_i, P, train=False, dropout_masks=None, vgg_fn=None):
     pre = "visual_net."
     B, V, Pc = images.shape[:3]
-    raw = vgg16_forward(images.reshape(B * V * Pc, *images.shape[3:]), P, pre + "vgg16.0.", train, dropout_masks)
+    flat = images.reshape(B * V * Pc, *images.shape[3:])
+    raw = vgg_fn(flat) if vgg_fn is not None else vgg16_forward(flat, P, pre + "vgg16.0.", train, dropout_masks)
     img = raw.view(B, V, Pc, -1).mean(dim=-2)
     w, b = P[pre + "linear.weight"], P[pre + "linear.bias"]
     img_emb = F.linear(img, w, b).squeeze(-1)
@@ -226,7 +227,7 @@ def review_net(user_emb, item_emb, u_lengths, i_lengths, P, aten=False, keep=Non
 
 
 def umpr_forward(P: Dict[str, Tensor], batch, *, review_net_only: bool, threshold=0.35, loss_v_rate=0.1,
-                 train=False, dropout_masks=None, aten=False, keep: Optional[dict] = None):
+                 train=False, dropout_masks=None, aten=False, keep: Optional[dict] = None, vgg_fn=None):
     """UMPR.forward, src/model.py:257-278.  ``batch`` is the 8-tuple src/dataset.py:173-182 builds."""
     user_reviews, item_reviews, ui_reviews, u_len, i_len, ui_len, photos, labels = batch
     emb = P["embedding.weight"]
@@ -238,7 +239,7 @@ def umpr_forward(P: Dict[str, Tensor], batch, *, review_net_only: bool, threshol
         loss = F.mse_loss(pred, labels, reduction="mean")
         return pred, loss
     c_u, c_i, prefer_pos, prefer_neg, kc = control_net(user_emb, item_emb, ui_emb, u_len, i_len, ui_len, P, threshold, aten)
-    pos_match, neg_match, final_pos, final_neg, img = visual_net(photos, c_u, c_i, P, train, dropout_masks)
+    pos_match, neg_match, final_pos, final_neg, img = visual_net(photos, c_u, c_i, P, train, dropout_masks, vgg_fn)
     pred = F.relu(F.linear(torch.cat([rr, final_pos, final_neg], dim=-1), w, b)).squeeze(-1)
     loss_r = F.mse_loss(pred, labels, reduction="mean")
     loss_v = torch.mean(prefer_pos.transpose(-1, -2) @ pos_match + prefer_neg.transpose(-1, -2) @ neg_match)

@@ -1,0 +1,92 @@
+"""Data-parallel host logic on CPU with gloo, world_size 2 (the N>1 path of bench.py / train.py).
+
+What is pinned: contiguous dim-0 sharding (DataParallel's scatter, main.py:82), per-shard forward/backward, SUM
+all-reduce of flat gradient arenas scaled by 1/world, mean of shard losses - against fixture dp_shards.npz, which the
+reference's own module produced shard by shard (tests/golden/make_golden.py::gen_dataparallel).  The per-shard model
+here is the oracle (CPU); the HIP model replaces it on GPUs, the collective logic is the same code
+(umpr_amd/parallel.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle import umpr_ref as R
+    from umpr_amd import parallel
+    from umpr_amd.synthetic import make_batch, make_param_state
+    r, _, w = parallel.init_distributed(backend="gloo")
+    g = load_golden("dp_shards")
+    P = make_param_state(41, 50, 1000, 1, False, with_vgg=False, m_scale=0.05)
+    names = [k for k in P if k != "embedding.weight"]
+    for k in names:
+        P[k].requires_grad_(True)
+    batch = make_batch(42, 4, 1000, 1, img_hw=8)
+    shard = parallel.shard_batch(batch, r, w)
+    assert shard[0].shape[0] == 2
+    fake_w = torch.from_numpy(g["fake_vgg_w"])
+    pred, loss = R.umpr_forward(P, shard, review_net_only=False, aten=True,
+                                vgg_fn=lambda im: F.linear(im.flatten(1), fake_w))
+    loss.backward()
+    # flat arena like umpr_amd.optim: one buffer, grads are slices of it
+    arena = torch.cat([P[k].grad.reshape(-1) for k in names])
+    parallel.allreduce_arenas([arena], n_buckets=3)
+    arena /= w
+    lsum, = parallel.allreduce_scalars([loss.item()], torch.device("cpu"))
+    if r == 0:
+        off = 0
+        res = {"loss": lsum / w}
+        for k in names:
+            n = P[k].numel()
+            res[k] = arena[off:off + n].reshape(P[k].shape).clone()
+            off += n
+        res["pred0"] = pred.detach()
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dataparallel_semantics_gloo(tmp_path):
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=True)
+    g = load_golden("dp_shards")
+    assert abs(res["loss"] - float(g["loss"])) < 1e-5
+    np.testing.assert_allclose(res["pred0"].numpy(), g["prediction"][:2], atol=1e-5)
+    checked = 0
+    for k, v in res.items():
+        if "grad/" + k in g:
+            ref = g["grad/" + k]
+            np.testing.assert_allclose(v.numpy(), ref, atol=1e-4 * float(np.abs(ref).max()) + 1e-7, rtol=1e-3, err_msg=k)
+            checked += 1
+    assert checked > 20
+
+
+def test_shard_batch_matches_chunk():
+    from umpr_amd import parallel
+    from umpr_amd.synthetic import make_batch
+    b = make_batch(3, 5, 100, 1, img_hw=8)
+    for world in (2, 3):
+        parts = [parallel.shard_batch(b, r, world) for r in range(world)]
+        for i, t in enumerate(b):
+            ref = torch.chunk(t, world, dim=0)
+            for r in range(len(ref)):
+                assert torch.equal(parts[r][i], ref[r])
