@@ -392,7 +392,8 @@ def _compare_golden(g, model, pred, loss):
             # an fp64 run) that the reference's fp32 CPU path itself is ~7e-4 of the tensor max away from the truth
             # there, and that the HIP path is at least as close - so two fp32 paths may differ by a few 1e-3.
             vggp = "vgg16" in k
-            check("grad " + k, p.grad, g["grad/" + k], atol=1e-6, rel_to_max=5e-3 if early else 2e-3,
+            first = k.endswith("features.0.weight")  # sum of n*224*224 cancelling terms: the noisiest tensor
+            check("grad " + k, p.grad, g["grad/" + k], atol=1e-6, rel_to_max=1e-2 if first else (5e-3 if early else 2e-3),
                   max_bad_frac=1e-3 if vggp else 0.0, max_bad=2 if vggp else 0,
                   rel_l2=(1e-2 if k.endswith("features.0.weight") else 5e-3) if vggp else None)
         elif "gradstat/" + k in g:

@@ -1,6 +1,7 @@
 // extern "C" entry points of libumpr_hip.so (declared in include/umpr_hip.h) and the composite ops they launch.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -386,6 +387,8 @@ int umpr_vgg16_bwd(const float* images, const float* const* params, int n, int t
     g = cur; float* t = cur; cur = oth; oth = t;
   }
   // ---- features, last block first.  g = d(pool5 output)
+  // (Tried: wgrad on a side stream so that its grid fills the tail of the dgrad grid - no gain at batch 64, 67.4 vs
+  //  67.2 ms/step, and the per-kernel event timing loses meaning under overlap; dropped.)
   int ci = 12;
   for (int b = 4; b >= 0; --b) {
     const int hw = L.conv_hw[ci];

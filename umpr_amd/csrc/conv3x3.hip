@@ -724,6 +724,130 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_v2_kernel(WgradParams p)
   }
 }
 
+// wgrad for Cin <= 3 (the first VGG layer, RGB input): the 9*Cin <= 27 (channel, tap) pairs become the 32 columns
+// of ONE accumulator tile instead of nine tiles with 3 of 32 columns in use.  Lane j = ci*9 + tap reads the patch at
+// ci*PL + (tap/3)*RW + tap%3 (+ pixel offset as an immediate); lanes >= 9*Cin compute garbage that is never stored.
+// Segment geometry R x CW as in the general kernel.  64 cout per workgroup: wave w owns couts 32*(w&1).. and pixel
+// pairs of parity (w>>1) (two half-K chains, summed through LDS at the end).
+template <int R, int CW>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgradParams p) {
+  constexpr int RW = CW + 2, PP = (R + 2) * RW, PL = PP | 1, NPX = R * CW;
+  static_assert((CW & 1) == 0 && NPX <= 32 && PP <= 102, "segment geometry");
+  __shared__ float Gs[2][64 * WG_LDG];
+  __shared__ float Xs[2][4 * PL];
+  __shared__ float Red[2][32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wk = wave >> 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int co0 = blockIdx.y * 64;
+  const int split = blockIdx.z;
+  const int H = p.H, W = p.W, HW = H * W;
+  const int gpx = tid & 31, gco = tid >> 5;
+  const int gr = gpx / CW, gc = gpx - gr * CW;
+  // patch staging: thread -> (channel, position), 3*PP <= 306 elements: two passes
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) bsum[v] = 0.f;
+  const int sbeg = split * p.segs_per_split;
+  const int send = min(p.nsegs, sbeg + p.segs_per_split);
+  float rg[8], rx[2];
+  unsigned okg = 0, okx = 0;
+  auto load = [&](int seg) {
+    const int sx = seg % p.segs_x;
+    const int sy = (seg / p.segs_x) % p.segs_y;
+    const int n = seg / (p.segs_x * p.segs_y);
+    const int y0 = sy * R, x0 = sx * CW;
+    okg = 0; okx = 0;
+    const bool ok = gpx < NPX && y0 + gr < H && x0 + gc < W;
+    const long base = (((long)n * p.Cout + co0 + gco) * H + y0 + gr) * W + x0 + gc;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const bool okv = ok && co0 + gco + 8 * v < p.Cout;
+      rg[v] = p.gz[okv ? base + (long)v * 8 * HW : 0];
+      okg |= (unsigned)okv << v;
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int e = tid + 256 * v;
+      const int ci = e / PP, pos = e - ci * PP;
+      const int prr = pos / RW, pcc = pos - prr * RW;
+      const int yy = y0 - 1 + prr, xx = x0 - 1 + pcc;
+      const bool okv = ci < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      rx[v] = p.x[okv ? (((long)n * p.Cin + ci) * H + yy) * W + xx : 0];
+      okx |= (unsigned)okv << v;
+    }
+  };
+  auto store = [&](int buf, bool fresh) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const float gv = ((okg >> v) & 1) ? rg[v] : 0.f;
+      Gs[buf][(gco + 8 * v) * WG_LDG + gpx] = gv;
+      bsum[v] += fresh ? gv : 0.f;
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int e = tid + 256 * v;
+      const int ci = e / PP, pos = e - ci * PP;
+      if (ci < 4) Xs[buf][ci * PL + pos] = ((okx >> v) & 1) ? rx[v] : 0.f;
+    }
+  };
+  // lane's (channel, tap) column
+  const int jc = l31 / 9, jt = l31 - jc * 9;
+  const int xcol = (jc < 3 ? jc : 3) * PL + (jt / 3) * RW + (jt % 3) + kh;
+  if (sbeg < send) { load(sbeg); store(0, true); }
+  __syncthreads();
+  for (int s = sbeg; s < send; ++s) {
+    const int cur = (s - sbeg) & 1;
+    load(min(s + 1, send - 1));
+    const float* gs = Gs[cur] + (wm * 32 + l31) * WG_LDG + kh;
+    const float* xs = Xs[cur] + xcol;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int kk = 2 * q + wk;                   // this wave's half of the 16 pixel pairs
+      const int px = 2 * kk;
+      const int po = (px / CW) * RW + (px % CW);
+      // wk is wave-uniform but not a compile-time constant: both candidates are immediates, select by wk
+      const int px0 = 2 * (2 * q), px1 = 2 * (2 * q + 1);
+      const int po0 = (px0 / CW) * RW + (px0 % CW), po1 = (px1 / CW) * RW + (px1 % CW);
+      const float a = wk ? gs[px1] : gs[px0];
+      const float b = wk ? xs[po1] : xs[po0];
+      (void)px; (void)po;
+      acc = mfma32(a, b, acc);
+    }
+    store(cur ^ 1, s + 1 < send);
+    __syncthreads();
+  }
+  // combine the two pixel-parity chains: waves 2,3 -> LDS -> waves 0,1
+  if (wk == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Red[wm][mfma_row(r, lane) * 33 + l31] = acc[r];
+  }
+  __syncthreads();
+  if (wk == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mfma_row(r, lane);
+      const float v = acc[r] + Red[wm][row * 33 + l31];
+      const int co = co0 + wm * 32 + row;
+      if (co < p.Cout && jc < p.Cin && l31 < 9 * p.Cin)
+        p.slab[(((long)split * 9 + jt) * p.Cout + co) * p.Cin + jc] = v;
+    }
+  }
+  if (p.bslab) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      float sv = bsum[v];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+      const int co = co0 + gco + 8 * v;
+      if (gpx == 0 && co < p.Cout) p.bslab[(long)split * p.Cout + co] = sv;
+    }
+  }
+}
+
 // dW[co][ci][t] (+)= sum_split slab[split][t][co][ci];  db[co] (+)= sum_split bslab[split][co]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, int splits,
                                     int Cout, int Cin, float* __restrict__ dw, float* __restrict__ db, int accumulate) {
@@ -864,6 +988,8 @@ int umpr_conv3x3_flip_transpose(const float* w, float* wt, int Cout, int Cin, hi
   return 0;
 }
 
+constexpr int kWgradTargetWgs = 1024;  // workgroups per wgrad launch (2 resident per CU): split-K factor = this / tiles
+
 // pixel segment = R rows x CW columns with R*CW <= 32: full MFMA k-utilisation when W is a multiple of 32/16/8
 static void wgrad_geometry(int W, int* R, int* CW) {
   if (W % 32 == 0) { *R = 1; *CW = 32; }
@@ -878,7 +1004,7 @@ size_t umpr_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
   wgrad_geometry(W, &R, &CW);
   const int nsegs = N * cdiv(H, R) * cdiv(W, CW);
   const int tiles = cdiv(Cout, 64) * cdiv(Cin, 64);
-  int splits = cdiv(1024, tiles);
+  int splits = cdiv(kWgradTargetWgs, tiles);
   if (splits > nsegs) splits = nsegs;
   return (size_t)splits * ((size_t)9 * Cout * Cin + Cout) * sizeof(float);
 }
@@ -893,7 +1019,7 @@ int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, in
   p.segs_x = cdiv(W, p.CW);
   p.nsegs = N * p.segs_y * p.segs_x;
   const int tiles = cdiv(Cout, 64) * cdiv(Cin, 64);
-  int splits = cdiv(1024, tiles);
+  int splits = cdiv(kWgradTargetWgs, tiles);
   if (splits > p.nsegs) splits = p.nsegs;
   const size_t per = ((size_t)9 * Cout * Cin + Cout) * sizeof(float);
   if ((size_t)splits * per > ws_bytes) splits = (int)(ws_bytes / per);
@@ -906,6 +1032,8 @@ int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, in
   {
     UmprProfScope prof(UMPR_K_CONV_WGRAD, 2.0 * N * H * W * Cout * Cin * 9, s);
     if (g_conv_force_v1) conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(p);
+    else if (Cin <= 3 && p.R == 1 && p.CW == 32) conv3x3_wgrad_c3_kernel<1, 32><<<grid, 256, 0, s>>>(p);
+    else if (Cin <= 3 && p.R == 2 && p.CW == 16) conv3x3_wgrad_c3_kernel<2, 16><<<grid, 256, 0, s>>>(p);
     else if (p.R == 1 && p.CW == 32) conv3x3_wgrad_v2_kernel<1, 32><<<grid, 256, 0, s>>>(p);
     else if (p.R == 2 && p.CW == 16) conv3x3_wgrad_v2_kernel<2, 16><<<grid, 256, 0, s>>>(p);
     else if (p.R == 4 && p.CW == 8) conv3x3_wgrad_v2_kernel<4, 8><<<grid, 256, 0, s>>>(p);

@@ -82,10 +82,11 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdParams p) {
     float gxr[3][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      // unconditional (clamped) loads: a per-lane `act ? load : 0` makes hipcc branch and wait per load
       const bool act = t < lreg[r];
-      const float* g = p.gx + ((long)nreg[r] * p.L + t) * 384 + dir * G3 + hid;
+      const float* g = p.gx + (act ? ((long)nreg[r] * p.L + t) * 384 + dir * G3 + hid : 0);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) gxr[q][r] = act ? g[q * H] : 0.f;
+      for (int q = 0; q < 3; ++q) gxr[q][r] = g[q * H];
     }
     f32x16 acc[3];
 #pragma unroll
@@ -191,18 +192,30 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
     const int t = dir == 0 ? maxlen - 1 - step : step;
     const int tp = dir == 0 ? t - 1 : t + 1;
     float dcarry[16];
+    // all loads of the step first, unconditionally (clamped addresses), then the gate math with selects
+    float ldo[16], lhp[16], lsv[4][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool act = t < lreg[r];
+      const bool hasp = act && tp >= 0 && tp < lreg[r];
+      const long orow = ((long)dreg[r] * p.L) * 128 + dir * H + hid;
+      ldo[r] = p.dout[act ? orow + (long)t * 128 : 0];
+      lhp[r] = p.out[hasp ? orow + (long)tp * 128 : 0];
+      const float* sv = p.saved + (act ? ((((long)dir * p.N + nreg[r]) * p.L + t) * 4) * H + hid : 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lsv[q][r] = sv[q * H];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int seq = ws * 32 + mfma_row(r, lane);
       const bool act = t < lreg[r];
-      float drp = 0.f, dzp = 0.f, dghn = 0.f, hp = 0.f;
+      const bool hasp = act && tp >= 0 && tp < lreg[r];
+      float drp = 0.f, dzp = 0.f, dghn = 0.f;
+      const float hp = hasp ? lhp[r] : 0.f;
       dcarry[r] = dh[r];
       if (act) {
-        const long orow = ((long)dreg[r] * p.L) * 128 + dir * H + hid;
-        const float dtot = dh[r] + p.dout[orow + (long)t * 128];
-        if (tp >= 0 && tp < lreg[r]) hp = p.out[orow + (long)tp * 128];
-        const float* sv = p.saved + ((((long)dir * p.N + nreg[r]) * p.L + t) * 4) * H + hid;
-        const float rr = sv[0], zz = sv[H], nn = sv[2 * H], hn = sv[3 * H];
+        const float dtot = dh[r] + ldo[r];
+        const float rr = lsv[0][r], zz = lsv[1][r], nn = lsv[2][r], hn = lsv[3][r];
         const float dnp = dtot * (1.f - zz) * (1.f - nn * nn);
         dzp = dtot * (hp - nn) * zz * (1.f - zz);
         drp = dnp * hn * rr * (1.f - rr);
