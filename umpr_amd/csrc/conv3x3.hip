@@ -191,9 +191,16 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvParams p) {
 //    stage body is branch-free; 2 waves/SIMD (launch bounds) let one workgroup's staging overlap the other's MFMAs.
 constexpr int V2_CC = 4, V2_KC = V2_CC * 9;
 
-template <int BM, int W, int PR>
-__global__ __launch_bounds__(256, 2) void conv3x3_igemm_v2_kernel(ConvParams p) {
-  constexpr int BN = 128, CC = V2_CC, KC = V2_KC;
+// rows of the halo patch a BN-pixel tile can touch on a WxW map: rows spanned inside one image, +2 when a tile can
+// straddle two images (virtual rows insert two zero rows between images), +2 halo
+constexpr int v2_patch_rows(int W, int BN) {
+  return ((BN - 1 + W - 1) / W + 1) + (((W * W) % BN) ? 2 : 0) + 2;
+}
+
+template <int BM, int BN, int W>
+__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv3x3_igemm_v2_kernel(ConvParams p) {
+  constexpr int PR = v2_patch_rows(W, BN);
+  constexpr int CC = V2_CC, KC = V2_KC;
   constexpr int RW = W + 2, PLANE = PR * RW;
   constexpr int LDA = BM + 2;
   constexpr int VEC = (W % 4 == 0) ? 4 : 2;
@@ -279,43 +286,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_v2_kernel(ConvParams p) 
   float4 ra[AV];
   float4 rb[BV];
   unsigned okb = 0;
-  auto load = [&](int s) {
-    okb = 0;
-#pragma unroll
-    for (int v = 0; v < AV; ++v) ra[v] = *reinterpret_cast<const float4*>(asrc[v] + s * KC);
-#pragma unroll
-    for (int v = 0; v < BV; ++v) {
-      const bool ok = bsrc[v] >= 0 && s * CC + bch[v] < p.C;
-      const float* src = p.x + (ok ? bsrc[v] + (long)s * CC * HW : 0);
-      if (VEC == 4) {
-        rb[v] = *reinterpret_cast<const float4*>(src);
-      } else {
-        const float2 t2 = *reinterpret_cast<const float2*>(src);
-        rb[v] = make_float4(t2.x, t2.y, 0.f, 0.f);
-      }
-      okb |= (unsigned)ok << v;
+  // staging is cut into AV+BV load pieces and AV+BV store pieces; inside the stage loop ONE piece follows each MFMA
+  // group slot, so a wave's staging instructions issue while its own MFMAs execute (at 1-2 waves/SIMD the other
+  // wave does not reliably cover them: ablation showed 17% of the kernel was exposed staging)
+  auto load_a = [&](int v, int s) { ra[v] = *reinterpret_cast<const float4*>(asrc[v] + s * KC); };
+  auto load_b = [&](int v, int s) {
+    const bool ok = bsrc[v] >= 0 && s * CC + bch[v] < p.C;
+    const float* src = p.x + (ok ? bsrc[v] + (long)s * CC * HW : 0);
+    if (VEC == 4) {
+      rb[v] = *reinterpret_cast<const float4*>(src);
+    } else {
+      const float2 t2 = *reinterpret_cast<const float2*>(src);
+      rb[v] = make_float4(t2.x, t2.y, 0.f, 0.f);
     }
+    okb = (okb & ~(1u << v)) | ((unsigned)ok << v);
   };
-  auto store = [&](int buf) {
-#pragma unroll
-    for (int v = 0; v < AV; ++v) {
-      float* S = As[buf] + adst[v];
-      S[0] = ra[v].x; S[LDA] = ra[v].y; S[2 * LDA] = ra[v].z; S[3 * LDA] = ra[v].w;
-    }
-#pragma unroll
-    for (int v = 0; v < BV; ++v) {
-      const bool ok = (okb >> v) & 1;
-      float* S = Ps[buf] + bdst[v];
-      S[0] = ok ? rb[v].x : 0.f; S[1] = ok ? rb[v].y : 0.f;
-      if (VEC == 4) { S[2] = ok ? rb[v].z : 0.f; S[3] = ok ? rb[v].w : 0.f; }
-    }
+  auto store_a = [&](int v, int buf) {
+    float* S = As[buf] + adst[v];
+    S[0] = ra[v].x; S[LDA] = ra[v].y; S[2 * LDA] = ra[v].z; S[3 * LDA] = ra[v].w;
   };
+  auto store_b = [&](int v, int buf) {
+    const bool ok = (okb >> v) & 1;
+    float* S = Ps[buf] + bdst[v];
+    S[0] = ok ? rb[v].x : 0.f; S[1] = ok ? rb[v].y : 0.f;
+    if (VEC == 4) { S[2] = ok ? rb[v].z : 0.f; S[3] = ok ? rb[v].w : 0.f; }
+  };
+  constexpr int NPIECE = AV + BV;
+  constexpr int KS = KC / 2;                      // MFMA k-steps per stage (18)
+  constexpr int ST0 = KS - NPIECE;                // first k-step that carries a store piece
+  static_assert(2 * NPIECE <= KS, "staging pieces must fit the k-steps of one stage");
 
-  load(0);
-  store(0);
+#pragma unroll
+  for (int v = 0; v < AV; ++v) load_a(v, 0);
+#pragma unroll
+  for (int v = 0; v < BV; ++v) load_b(v, 0);
+#pragma unroll
+  for (int v = 0; v < AV; ++v) store_a(v, 0);
+#pragma unroll
+  for (int v = 0; v < BV; ++v) store_b(v, 0);
   __syncthreads();
   // outer loop = one MFMA accumulation chain (SFLUSH stages): inside it the accumulators are written only by MFMAs
-  // and stay in AGPRs (a conditional fold inside the stage loop made hipcc move all of them through VGPRs per stage)
+  // (a conditional fold inside the stage loop made hipcc move all of them between register files every stage)
   for (int s0 = 0; s0 < ns; s0 += SFLUSH) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -326,33 +337,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_v2_kernel(ConvParams p) 
     const int s1 = min(ns, s0 + SFLUSH);
     for (int s = s0; s < s1; ++s) {
       const int cur = s & 1;
-      load(min(s + 1, ns - 1));              // the last stage re-loads itself: keeps the body branch-free
+      const int sn = min(s + 1, ns - 1);          // the last stage re-loads itself: keeps the body branch-free
       const float* as = As[cur] + half * LDA + wm * WTM + l31;
       const float* ps = Ps[cur];
-      // software-pipelined fragment reads: the LDS reads of step kk+1 are in flight while the MFMAs of step kk run
       float a[2][TM], b[2][TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[0][j] = ps[boff[j]];
 #pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) {
+      for (int kk = 0; kk < KS; ++kk) {
         const int cb = kk & 1, nb = cb ^ 1;
-        if (kk + 1 < KC / 2) {
-          const int k1 = kk + 1, cl = k1 / 9, tap = k1 % 9;
+        const int k1 = kk + 1, cl = k1 / 9, tap = k1 % 9;
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[nb][i] = as[2 * k1 * LDA + i * 32];
+        for (int m = 0; m < TM * TN; ++m) {
+          const int i = m / TN, j = m % TN;
+          acc[i][j] = mfma32(a[cb][i], b[cb][j], acc[i][j]);
+          // what rides behind this MFMA
+          if (m == 0 && kk + 1 < KS) {            // fragment reads of the next step: A ...
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[nb][j] = ps[boff[j] + cl * PLANE + (tap / 3) * RW + (tap % 3)];
+            for (int ii = 0; ii < TM; ++ii) a[nb][ii] = as[2 * k1 * LDA + ii * 32];
+          }
+          if (m == (TM * TN > 1 ? 1 : 0) && kk + 1 < KS) {  // ... and B
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) b[nb][jj] = ps[boff[jj] + cl * PLANE + (tap / 3) * RW + (tap % 3)];
+          }
+          if (m == TM * TN - 1) {                 // one staging piece per k-step
+            if (kk < AV) load_a(kk, sn);
+            else if (kk < NPIECE) load_b(kk - AV, sn);
+            else if (kk >= ST0 && kk - ST0 < AV) store_a(kk - ST0, cur ^ 1);
+            else if (kk >= ST0 + AV) store_b(kk - ST0 - AV, cur ^ 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);      // pin: hipcc would otherwise regroup loads/reads/MFMAs
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this step's MFMAs
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[cb][i], b[cb][j], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
       }
-      store(cur ^ 1);
       __syncthreads();
     }
 #pragma unroll
@@ -404,15 +422,18 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-template <int W, int PR>
-void launch_v2(const ConvParams& p, hipStream_t s) {
+template <int W>
+void launch_v2(const ConvParams& p, int bn, hipStream_t s) {
   const long NP = (long)p.N * p.H * p.W;
   if (p.Cout <= 64) {
     dim3 grid(cdiv(NP, 128), cdiv(p.Cout, 64));
-    conv3x3_igemm_v2_kernel<64, W, PR><<<grid, 256, 0, s>>>(p);
+    conv3x3_igemm_v2_kernel<64, 128, W><<<grid, 256, 0, s>>>(p);
+  } else if (bn == 64) {
+    dim3 grid(cdiv(NP, 64), cdiv(p.Cout, 128));
+    conv3x3_igemm_v2_kernel<128, 64, W><<<grid, 256, 0, s>>>(p);
   } else {
     dim3 grid(cdiv(NP, 128), cdiv(p.Cout, 128));
-    conv3x3_igemm_v2_kernel<128, W, PR><<<grid, 256, 0, s>>>(p);
+    conv3x3_igemm_v2_kernel<128, 128, W><<<grid, 256, 0, s>>>(p);
   }
 }
 
@@ -624,59 +645,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_v2_kernel(WgradParams p)
   float rx[CPG];
   unsigned okg = 0, okx = 0;
 
-  auto load = [&](int seg) {
+  // staging in pieces (one global load or one LDS store each); inside the segment loop one piece rides behind every
+  // MFMA, loads in the first slots and stores in the last, so they issue while this wave's MFMAs execute
+  int cy0 = 0, cx0 = 0; long cgb = 0, cxb = 0; bool cgo = false, cxo = false;
+  auto seg_setup = [&](int seg) {
     const int sx = seg % p.segs_x;
     const int sy = (seg / p.segs_x) % p.segs_y;
     const int n = seg / (p.segs_x * p.segs_y);
-    const int y0 = sy * R, x0 = sx * CW;
+    cy0 = sy * R; cx0 = sx * CW;
+    cgo = gpx < NPX && cy0 + gr < H && cx0 + gc < W;
+    cgb = (((long)n * p.Cout + co0 + gco) * H + cy0 + gr) * W + cx0 + gc;
+    const int yy = cy0 - 1 + prr, xx = cx0 - 1 + pcc;
+    cxo = pact && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    cxb = (((long)n * p.Cin + ci0 + pg) * H + yy) * W + xx;
     okg = 0; okx = 0;
-    {
-      const bool ok = gpx < NPX && y0 + gr < H && x0 + gc < W;
-      const long base = (((long)n * p.Cout + co0 + gco) * H + y0 + gr) * W + x0 + gc;
-#pragma unroll
-      for (int v = 0; v < 8; ++v) {
-        const bool okv = ok && co0 + gco + 8 * v < p.Cout;
-        rg[v] = p.gz[okv ? base + (long)v * 8 * HW : 0];
-        okg |= (unsigned)okv << v;
-      }
-    }
-    {
-      const int yy = y0 - 1 + prr, xx = x0 - 1 + pcc;
-      const bool ok = pact && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const long base = (((long)n * p.Cin + ci0 + pg) * H + yy) * W + xx;
-#pragma unroll
-      for (int v = 0; v < CPG; ++v) {
-        const int ci = pg + G * v;
-        const bool okv = ok && ci < 64 && ci0 + ci < p.Cin;
-        rx[v] = p.x[okv ? base + (long)v * G * HW : 0];
-        okx |= (unsigned)okv << v;
-      }
-    }
   };
-  auto store = [&](int buf, bool fresh) {  // fresh = false for the redundant re-load of the last segment
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const float gv = ((okg >> v) & 1) ? rg[v] : 0.f;
-      Gs[buf][(gco + 8 * v) * WG_LDG + gpx] = gv;
-      bsum[v] += fresh ? gv : 0.f;
-    }
-    if (pact) {
-#pragma unroll
-      for (int v = 0; v < CPG; ++v) {
-        const int ci = pg + G * v;
-        if (ci < 64) Xs[buf][ci * PL + pos] = ((okx >> v) & 1) ? rx[v] : 0.f;
-      }
-    }
+  auto load_g = [&](int v) {
+    const bool okv = cgo && co0 + gco + 8 * v < p.Cout;
+    rg[v] = p.gz[okv ? cgb + (long)v * 8 * HW : 0];
+    okg |= (unsigned)okv << v;
   };
+  auto load_x = [&](int v) {
+    const int ci = pg + G * v;
+    const bool okv = cxo && ci < 64 && ci0 + ci < p.Cin;
+    rx[v] = p.x[okv ? cxb + (long)v * G * HW : 0];
+    okx |= (unsigned)okv << v;
+  };
+  auto store_g = [&](int v, int buf, bool fresh) {
+    const float gv = ((okg >> v) & 1) ? rg[v] : 0.f;
+    Gs[buf][(gco + 8 * v) * WG_LDG + gpx] = gv;
+    bsum[v] += fresh ? gv : 0.f;
+  };
+  auto store_x = [&](int v, int buf) {
+    const int ci = pg + G * v;
+    if (pact && ci < 64) Xs[buf][ci * PL + pos] = ((okx >> v) & 1) ? rx[v] : 0.f;
+  };
+  constexpr int NP_ = 8 + CPG;                  // pieces of each kind per segment
+  constexpr int NSLOT = 16 * 9;
+  static_assert(2 * NP_ <= NSLOT, "pieces must fit the MFMA slots of one segment");
 
   if (sbeg < send) {
-    load(sbeg);
-    store(0, true);
+    seg_setup(sbeg);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) load_g(v);
+#pragma unroll
+    for (int v = 0; v < CPG; ++v) load_x(v);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) store_g(v, 0, true);
+#pragma unroll
+    for (int v = 0; v < CPG; ++v) store_x(v, 0);
   }
   __syncthreads();
   for (int s = sbeg; s < send; ++s) {
     const int cur = (s - sbeg) & 1;
-    load(min(s + 1, send - 1));
+    const bool fresh = s + 1 < send;            // the last segment re-loads itself (branch-free body), not re-counted
+    seg_setup(min(s + 1, send - 1));
     const float* gs = Gs[cur] + (wm * 32 + l31) * WG_LDG + kh;
     const float* xs = Xs[cur] + (wn * 32 + l31) * PL + kh;
     float a[2], b[2][9];
@@ -686,20 +709,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_v2_kernel(WgradParams p)
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       const int cb = kk & 1, nb = cb ^ 1;
-      if (kk + 1 < 16) {
-        constexpr int dummy = 0; (void)dummy;
-        const int px = 2 * (kk + 1);              // even pixel of the pair; the odd one is +1 (CW even)
-        const int po = (px / CW) * RW + (px % CW);
-        a[nb] = gs[px];
+      const int px = 2 * (kk + 1);                // even pixel of the next pair; the odd one is +1 (CW even)
+      const int po = (px / CW) * RW + (px % CW);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) b[nb][t] = xs[po + (t / 3) * RW + (t % 3)];
+      for (int t = 0; t < 9; ++t) {
+        acc[t] = mfma32(a[cb], b[cb][t], acc[t]);
+        if (kk + 1 < 16) {                        // next step's fragments, one read per MFMA
+          if (t == 0) a[nb] = gs[px];
+          b[nb][t] = xs[po + (t / 3) * RW + (t % 3)];
+        }
+        const int q = kk * 9 + t;                 // staging piece of this slot
+        if (q < 8) load_g(q);
+        else if (q < NP_) load_x(q - 8);
+        else if (q >= NSLOT - NP_ && q < NSLOT - CPG) store_g(q - (NSLOT - NP_), cur ^ 1, fresh);
+        else if (q >= NSLOT - CPG) store_x(q - (NSLOT - CPG), cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) acc[t] = mfma32(a[cb], b[cb][t], acc[t]);
-      __builtin_amdgcn_sched_barrier(0);
     }
-    store(cur ^ 1, s + 1 < send);
     __syncthreads();
   }
 
@@ -924,8 +950,9 @@ __global__ void maxpool2_bwd_relu_kernel(const float* __restrict__ x, const floa
 }  // namespace
 
 // ---- internal host entry points ------------------------------------------------------------------------------
+static int g_conv_bn = 128;  // UMPR_CONV_BN=64 selects 128x64 tiles (A/B runs)
 static bool g_conv_force_v1 = false;  // UMPR_CONV_V1=1 selects the generic gather kernel (A/B runs)
-static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; } } g_conv_env_init;
+static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; const char* q = getenv("UMPR_CONV_BN"); g_conv_bn = q ? atoi(q) : 128; } } g_conv_env_init;
 size_t umpr_conv3x3_pack_floats(int Cin, int Cout) {
   const size_t a = (size_t)Cout * ((Cin + V2_CC - 1) / V2_CC) * V2_KC;   // forward pack
   const size_t b = (size_t)Cin * ((Cout + V2_CC - 1) / V2_CC) * V2_KC;   // transposed pack
@@ -952,11 +979,11 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
     UMPR_LAUNCH_CHECK("pack_weights");
     ConvParams p{x, wpack, bias, mask, y, N, C, H, W, M, relu};
     UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
-    if (W == 224) launch_v2<224, 4>(p, s);
-    else if (W == 112) launch_v2<112, 5>(p, s);
-    else if (W == 56) launch_v2<56, 8>(p, s);
-    else if (W == 28) launch_v2<28, 10>(p, s);
-    else launch_v2<14, 15>(p, s);
+    if (W == 224) launch_v2<224>(p, g_conv_bn, s);
+    else if (W == 112) launch_v2<112>(p, g_conv_bn, s);
+    else if (W == 56) launch_v2<56>(p, g_conv_bn, s);
+    else if (W == 28) launch_v2<28>(p, g_conv_bn, s);
+    else launch_v2<14>(p, g_conv_bn, s);
     UMPR_LAUNCH_CHECK("conv3x3_igemm_v2");
     return 0;
   }
@@ -992,9 +1019,11 @@ constexpr int kWgradTargetWgs = 1024;  // workgroups per wgrad launch (2 residen
 
 // pixel segment = R rows x CW columns with R*CW <= 32: full MFMA k-utilisation when W is a multiple of 32/16/8
 static void wgrad_geometry(int W, int* R, int* CW) {
-  if (W % 32 == 0) { *R = 1; *CW = 32; }
-  else if (W % 16 == 0) { *R = 2; *CW = 16; }
+  // two-row segments keep the halo patch small (72 / 64 positions -> 22 / 16 loads per thread and no register spills;
+  // the one-row 32- and 28-wide variants needed 32 loads and spilled)
+  if (W % 16 == 0) { *R = 2; *CW = 16; }
   else if (W % 8 == 0) { *R = 4; *CW = 8; }
+  else if (W % 14 == 0) { *R = 2; *CW = 14; }
   else if (W < 32) { *R = 32 / W; *CW = W; }
   else { *R = 1; *CW = 32; }
 }
@@ -1032,12 +1061,9 @@ int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, in
   {
     UmprProfScope prof(UMPR_K_CONV_WGRAD, 2.0 * N * H * W * Cout * Cin * 9, s);
     if (g_conv_force_v1) conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(p);
-    else if (Cin <= 3 && p.R == 1 && p.CW == 32) conv3x3_wgrad_c3_kernel<1, 32><<<grid, 256, 0, s>>>(p);
     else if (Cin <= 3 && p.R == 2 && p.CW == 16) conv3x3_wgrad_c3_kernel<2, 16><<<grid, 256, 0, s>>>(p);
-    else if (p.R == 1 && p.CW == 32) conv3x3_wgrad_v2_kernel<1, 32><<<grid, 256, 0, s>>>(p);
     else if (p.R == 2 && p.CW == 16) conv3x3_wgrad_v2_kernel<2, 16><<<grid, 256, 0, s>>>(p);
     else if (p.R == 4 && p.CW == 8) conv3x3_wgrad_v2_kernel<4, 8><<<grid, 256, 0, s>>>(p);
-    else if (p.R == 1 && p.CW == 28) conv3x3_wgrad_v2_kernel<1, 28><<<grid, 256, 0, s>>>(p);
     else if (p.R == 2 && p.CW == 14) conv3x3_wgrad_v2_kernel<2, 14><<<grid, 256, 0, s>>>(p);
     else conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(p);
   }
