@@ -127,6 +127,7 @@ def main():
     model.load_state_dict(P)
     model = model.to(dev)
     opt = FusedAdam(model, cfg.learning_rate, cfg.l2_regularization, cfg.lr_decay)
+    reducer = parallel.GradReducer(opt) if world > 1 else None
     batch = to_device(make_batch(1234 + rank, args.batch, args.vocab, args.views, review_net_only=args.review_net_only,
                                  full_pad=not args.realistic), dev)
     loss_sum = torch.zeros((), device=dev)
@@ -138,14 +139,14 @@ def main():
 
     note("model and batch resident; warm-up")
     for _ in range(args.warmup):
-        train_step(model, opt, batch, world)
+        train_step(model, opt, batch, world, reducer)
     barrier()
     note("timed region")
     L.fn["umpr_profile_reset"]()
     L.fn["umpr_profile_enable"](1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, loss = train_step(model, opt, batch, world)
+        _, loss = train_step(model, opt, batch, world, reducer)
         loss_sum += loss.detach()
     barrier()
     dt = time.perf_counter() - t0

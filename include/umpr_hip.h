@@ -132,6 +132,21 @@ int umpr_vgg16_fwd(const float* images, const float* const* params, int n_img, i
 int umpr_vgg16_bwd(const float* images, const float* const* params, int n_img, int train, const float* acts,
                    const uint8_t* masks, const float* d_out, float* const* grads, float* ws, size_t ws_bytes,
                    void* stream);
+/* The same in two stages, so that a host can start exchanging the classifier gradients (89 % of all gradient bytes:
+ * fc1 alone is 411 MB) while the convolutional backward still runs.  pool5 = acts + umpr_vgg16_pool5_offset(n) bytes
+ * is the [n][512][7][7] output of the feature stage; d_pool5 [n][25088]. */
+size_t umpr_vgg16_pool5_offset(int n_img);
+int umpr_vgg16_features_fwd(const float* images, const float* const* params, int n_img, float* acts, float* ws,
+                            size_t ws_bytes, void* stream);
+int umpr_vgg16_classifier_fwd(const float* const* params, int n_img, int train, int use_masks, uint64_t seed,
+                              float* acts, uint8_t* masks, float* out, float* ws, size_t ws_bytes, void* stream);
+size_t umpr_vgg16_classifier_bwd_ws_bytes(int n_img);
+int umpr_vgg16_classifier_bwd(const float* const* params, int n_img, int train, const float* acts,
+                              const uint8_t* masks, const float* d_out, float* const* grads, float* d_pool5, float* ws,
+                              size_t ws_bytes, void* stream);
+size_t umpr_vgg16_features_bwd_ws_bytes(int n_img);
+int umpr_vgg16_features_bwd(const float* images, const float* const* params, int n_img, const float* acts,
+                            const float* d_pool5, float* const* grads, float* ws, size_t ws_bytes, void* stream);
 /* per-layer entry points (also what the composite calls) */
 /* wpack / wt: scratch of umpr_conv3x3_pack_bytes(Cin, Cout) - the kernels read the weights in a packed order */
 size_t umpr_conv3x3_pack_bytes(int Cin, int Cout);

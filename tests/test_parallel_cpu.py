@@ -90,3 +90,62 @@ def test_shard_batch_matches_chunk():
             ref = torch.chunk(t, world, dim=0)
             for r in range(len(ref)):
                 assert torch.equal(parts[r][i], ref[r])
+
+
+class _Tiny(torch.nn.Module):
+    """Parameter names shaped like the real model: a 'classifier' part whose gradients come first, a conv-like rest."""
+
+    def __init__(self):
+        super().__init__()
+        self.features = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 8))
+        self.classifier = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+
+    def forward(self, x):
+        return self.classifier(self.features(x))
+
+
+def _reducer_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from umpr_amd import parallel
+    from umpr_amd.optim import FusedAdam
+    parallel.init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    model = _Tiny()
+    opt = FusedAdam(model, 1e-3, 1e-3)
+    red = parallel.GradReducer(opt, n_buckets=3)
+    assert red.early is not None and red.hook is not None
+    names0 = opt.groups[0].names
+    assert "classifier." in names0[0] and "classifier." not in names0[-1], names0  # classifier slice leads the arena
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(5, 6, generator=g)
+    torch.manual_seed(0)
+    twin = _Tiny()                            # same weights, no reducer: source of the un-reduced local gradients
+    topt = FusedAdam(twin, 1e-3, 1e-3)
+    for it in range(2):                       # two steps: the hook must re-arm
+        opt.zero_grad()
+        model(x).pow(2).sum().backward()
+        assert red.fired, "early bucket did not start during backward"
+        topt.zero_grad()
+        twin(x).pow(2).sum().backward()
+        ref = [a.clone() for a in topt.grad_arenas()]   # reference: plain sum over ranks of the local arenas
+        red.finish()
+        for r in ref:
+            dist.all_reduce(r)
+        for a, r in zip(opt.grad_arenas(), ref):
+            assert torch.allclose(a, r, atol=1e-6), (it, (a - r).abs().max())
+        # params are views of the arenas: .grad of a parameter sees the reduced value
+        p = dict(model.named_parameters())["classifier.0.weight"]
+        off, n = opt.groups[0].offsets["classifier.0.weight"]
+        assert torch.equal(p.grad.reshape(-1), opt.groups[0].g[off:off + n])
+    if rank == 0:
+        torch.save({"ok": torch.tensor(1)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_grad_reducer_gloo(tmp_path):
+    out = str(tmp_path / "red.pt")
+    mp.spawn(_reducer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert os.path.exists(out)

@@ -47,6 +47,13 @@ SIGNATURES = {
     "umpr_vgg16_ws_bytes": ("i", "z"),
     "umpr_vgg16_fwd": ("ppiiiuppppzp", "i"),
     "umpr_vgg16_bwd": ("ppiipppppzp", "i"),
+    "umpr_vgg16_pool5_offset": ("i", "z"),
+    "umpr_vgg16_features_fwd": ("ppippzp", "i"),
+    "umpr_vgg16_classifier_fwd": ("piiiuppppzp", "i"),
+    "umpr_vgg16_classifier_bwd_ws_bytes": ("i", "z"),
+    "umpr_vgg16_classifier_bwd": ("piippppppzp", "i"),
+    "umpr_vgg16_features_bwd_ws_bytes": ("i", "z"),
+    "umpr_vgg16_features_bwd": ("ppippppzp", "i"),
     "umpr_conv3x3_pack_bytes": ("ii", "z"),
     "umpr_conv3x3_fwd": ("ppppiiiiiipp", "i"),
     "umpr_conv3x3_bwd_data": ("ppppiiiiipp", "i"),

@@ -281,9 +281,9 @@ constexpr size_t kWtFloats = (size_t)512 * 512 * 9 + 4096;  // >= umpr_conv3x3_p
 size_t umpr_vgg16_fwd_ws_bytes(int n_img) { return vgg_scratch_bytes(n_img); }
 
 size_t umpr_vgg16_ws_bytes(int n_img) {
-  // [gradient ping][gradient pong] (largest activation each) [flip-transposed weights][scratch]
+  // [d_pool5][gradient ping][gradient pong] (largest activation each) [packed weights][scratch]
   const size_t big = (size_t)n_img * 64 * 224 * 224;
-  return (2 * big + kWtFloats) * sizeof(float) + vgg_scratch_bytes(n_img);
+  return ((size_t)n_img * 25088 + 2 * big + kWtFloats) * sizeof(float) + vgg_scratch_bytes(n_img);
 }
 
 size_t umpr_conv3x3_pack_bytes(int Cin, int Cout) { return umpr_conv3x3_pack_floats(Cin, Cout) * sizeof(float); }
@@ -309,10 +309,12 @@ int umpr_maxpool2_bwd_relu(const float* x, const float* dy, float* dx, long plan
   return umpr_maxpool2_bwd_relu_impl(x, dy, dx, planes, H_, W, S(stream));
 }
 
-int umpr_vgg16_fwd(const float* images, const float* const* params, int n, int train, int use_masks, uint64_t seed,
-                   float* acts, uint8_t* masks, float* out, float* ws, size_t ws_bytes, void* stream) {
-  UMPR_REQUIRE(n > 0 && images && params && acts && out, "vgg16_fwd: bad arguments");
-  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_fwd_ws_bytes(n), "vgg16_fwd: workspace too small");
+size_t umpr_vgg16_pool5_offset(int n_img) { return vgg_layout(n_img).pool_off[4] * sizeof(float); }
+
+int umpr_vgg16_features_fwd(const float* images, const float* const* params, int n, float* acts, float* ws,
+                            size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(n > 0 && images && params && acts, "vgg16_features_fwd: bad arguments");
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_fwd_ws_bytes(n), "vgg16_features_fwd: workspace too small");
   const VggLayout L = vgg_layout(n);
   hipStream_t s = S(stream);
   const float* x = images;
@@ -330,7 +332,17 @@ int umpr_vgg16_fwd(const float* images, const float* const* params, int n, int t
     if (int rc = umpr_maxpool2_fwd_impl(x, y, (long)n * kBlockCh[b], hw, hw, s)) return rc;
     x = y;
   }
-  // classifier; AdaptiveAvgPool2d(7) is the identity on the 7x7 map a 224x224 image produces
+  return 0;
+}
+
+int umpr_vgg16_classifier_fwd(const float* const* params, int n, int train, int use_masks, uint64_t seed, float* acts,
+                              uint8_t* masks, float* out, float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(n > 0 && params && acts && out, "vgg16_classifier_fwd: bad arguments");
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_fwd_ws_bytes(n), "vgg16_classifier_fwd: workspace too small");
+  const VggLayout L = vgg_layout(n);
+  hipStream_t s = S(stream);
+  // AdaptiveAvgPool2d(7) is the identity on the 7x7 map a 224x224 image produces
+  const float* x = acts + L.pool_off[4];
   for (int j = 0; j < 3; ++j) {
     UmprGemm g;
     g.A = x; g.lda = kFc[j][0]; g.B = params[26 + 2 * j]; g.ldb = kFc[j][0]; g.transB = true;
@@ -349,26 +361,33 @@ int umpr_vgg16_fwd(const float* images, const float* const* params, int n, int t
   return 0;
 }
 
-int umpr_vgg16_bwd(const float* images, const float* const* params, int n, int train, const float* acts,
-                   const uint8_t* masks, const float* d_out, float* const* grads, float* ws, size_t ws_bytes,
-                   void* stream) {
-  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_ws_bytes(n), "vgg16_bwd: workspace too small (%zu < %zu)", ws_bytes,
-               umpr_vgg16_ws_bytes(n));
+int umpr_vgg16_fwd(const float* images, const float* const* params, int n, int train, int use_masks, uint64_t seed,
+                   float* acts, uint8_t* masks, float* out, float* ws, size_t ws_bytes, void* stream) {
+  if (int rc = umpr_vgg16_features_fwd(images, params, n, acts, ws, ws_bytes, stream)) return rc;
+  return umpr_vgg16_classifier_fwd(params, n, train, use_masks, seed, acts, masks, out, ws, ws_bytes, stream);
+}
+
+size_t umpr_vgg16_classifier_bwd_ws_bytes(int n_img) {
+  return (size_t)2 * n_img * 4096 * sizeof(float) + vgg_scratch_bytes(n_img);
+}
+
+// d_pool5 [n][25088] receives the gradient w.r.t. the pooled feature map; grads: the 32-pointer array (only the six
+// classifier entries 26..31 are written).
+int umpr_vgg16_classifier_bwd(const float* const* params, int n, int train, const float* acts, const uint8_t* masks,
+                              const float* d_out, float* const* grads, float* d_pool5, float* ws, size_t ws_bytes,
+                              void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_classifier_bwd_ws_bytes(n), "vgg16_classifier_bwd: workspace too small");
   const VggLayout L = vgg_layout(n);
   hipStream_t s = S(stream);
-  const size_t big = (size_t)n * 64 * 224 * 224;
   float* gA = ws;
-  float* gB = ws + big;
-  float* wt = gB + big;
-  float* scratch = wt + kWtFloats;
+  float* gB = ws + (size_t)n * 4096;
+  float* scratch = gB + (size_t)n * 4096;
   const size_t slab_bytes = vgg_scratch_bytes(n);
-  // ---- classifier
   const float* g = d_out;  // gradient w.r.t. the current layer's output
   float* cur = gA; float* oth = gB;
   for (int j = 2; j >= 0; --j) {
     const int fin = kFc[j][0], fout = kFc[j][1];
-    const float* xin = j == 0 ? acts + L.pool_off[4]
-                              : ((train ? acts + L.drop_off[j - 1] : acts + L.fc_off[j - 1]));
+    const float* xin = j == 0 ? acts + L.pool_off[4] : (train ? acts + L.drop_off[j - 1] : acts + L.fc_off[j - 1]);
     if (j < 2) {
       // g is d(dropout output or relu output); fold dropout mask and ReLU into gz
       if (int rc = umpr_dropout_bwd_impl(g, train ? masks + (size_t)j * n * 4096 : nullptr, acts + L.fc_off[j], cur,
@@ -381,14 +400,34 @@ int umpr_vgg16_bwd(const float* images, const float* const* params, int n, int t
     if (int rc = umpr_gemm(w, s)) return rc;
     if (int rc = umpr_colsum_rows(g, n, fout, fout, grads[27 + 2 * j], 0, s)) return rc;
     UmprGemm d;  // dx[n][fin] = g W
-    d.A = g; d.lda = fout; d.B = params[26 + 2 * j]; d.ldb = fin; d.C = cur; d.ldc = fin; d.M = n; d.N = fin; d.K = fout;
-    d.split_k = 0; d.ws = scratch; d.ws_bytes = slab_bytes;
+    d.A = g; d.lda = fout; d.B = params[26 + 2 * j]; d.ldb = fin; d.C = j == 0 ? d_pool5 : cur; d.ldc = fin; d.M = n;
+    d.N = fin; d.K = fout; d.split_k = 0; d.ws = scratch; d.ws_bytes = slab_bytes;
     if (int rc = umpr_gemm(d, s)) return rc;
-    g = cur; float* t = cur; cur = oth; oth = t;
+    g = d.C; float* t = cur; cur = oth; oth = t;
   }
-  // ---- features, last block first.  g = d(pool5 output)
-  // (Tried: wgrad on a side stream so that its grid fills the tail of the dgrad grid - no gain at batch 64, 67.4 vs
-  //  67.2 ms/step, and the per-kernel event timing loses meaning under overlap; dropped.)
+  return 0;
+}
+
+size_t umpr_vgg16_features_bwd_ws_bytes(int n_img) {
+  const size_t big = (size_t)n_img * 64 * 224 * 224;
+  return (2 * big + kWtFloats) * sizeof(float) + vgg_scratch_bytes(n_img);
+}
+
+int umpr_vgg16_features_bwd(const float* images, const float* const* params, int n, const float* acts,
+                            const float* d_pool5, float* const* grads, float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_features_bwd_ws_bytes(n), "vgg16_features_bwd: workspace too small");
+  const VggLayout L = vgg_layout(n);
+  hipStream_t s = S(stream);
+  const size_t big = (size_t)n * 64 * 224 * 224;
+  float* gA = ws;
+  float* gB = ws + big;
+  float* wt = gB + big;
+  float* scratch = wt + kWtFloats;
+  const size_t slab_bytes = vgg_scratch_bytes(n);
+  const float* g = d_pool5;
+  float* cur = gA; float* oth = gB;
+  // last block first.  (Tried: wgrad on a side stream so that its grid fills the tail of the dgrad grid - no gain at
+  // batch 64, 67.4 vs 67.2 ms/step, and per-kernel event timing loses meaning under overlap; dropped.)
   int ci = 12;
   for (int b = 4; b >= 0; --b) {
     const int hw = L.conv_hw[ci];
@@ -409,6 +448,20 @@ int umpr_vgg16_bwd(const float* images, const float* const* params, int n, int t
     if (ci == 0 && b == 0) break;
   }
   return 0;
+}
+
+int umpr_vgg16_bwd(const float* images, const float* const* params, int n, int train, const float* acts,
+                   const uint8_t* masks, const float* d_out, float* const* grads, float* ws, size_t ws_bytes,
+                   void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_ws_bytes(n), "vgg16_bwd: workspace too small (%zu < %zu)", ws_bytes,
+               umpr_vgg16_ws_bytes(n));
+  // d_pool5 lives at the front of the workspace; the stage workspaces follow it
+  float* d_pool5 = ws;
+  float* rest = ws + (size_t)n * 25088;
+  const size_t rest_bytes = ws_bytes - (size_t)n * 25088 * sizeof(float);
+  if (int rc = umpr_vgg16_classifier_bwd(params, n, train, acts, masks, d_out, grads, d_pool5, rest, rest_bytes, stream))
+    return rc;
+  return umpr_vgg16_features_bwd(images, params, n, acts, d_pool5, grads, rest, rest_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ head

@@ -710,7 +710,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_v2_kernel(WgradParams p)
     for (int kk = 0; kk < 16; ++kk) {
       const int cb = kk & 1, nb = cb ^ 1;
       const int px = 2 * (kk + 1);                // even pixel of the next pair; the odd one is +1 (CW even)
-      const int po = (px / CW) * RW + (px % CW);
+      // pixels past the segment (R*CW < 32) have gz = 0; read patch offset 0 for them: anything else could touch LDS
+      // that was never written and turn 0 * NaN into NaN
+      const int po = px < NPX ? (px / CW) * RW + (px % CW) : 0;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         acc[t] = mfma32(a[cb], b[cb][t], acc[t]);

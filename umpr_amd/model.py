@@ -217,40 +217,73 @@ def _ptr_array(tensors):
     return arr, ctypes.cast(arr, ctypes.c_void_p)
 
 
-class _VGG16(torch.autograd.Function):
-    """torchvision.models.vgg16 configuration D (call site src/model.py:204-207,217)."""
+class _VGGFeatures(torch.autograd.Function):
+    """Convolutional stage of torchvision.models.vgg16 configuration D (call site src/model.py:204-207,217).
+    Returns (pool5 [n,25088] - a view into the activation arena -, the arena itself)."""
 
     @staticmethod
-    def forward(ctx, images, train, masks_in, seed, *params):
+    def forward(ctx, images, *params):
         n = images.shape[0]
         assert tuple(images.shape[1:]) == (3, 224, 224), "VGG16 kernels take 3x224x224 images (src/dataset.py:146)"
         dev = images.device
         images = _c(images)
         params = [_c(p) for p in params]
         acts = torch.empty(lib().size("umpr_vgg16_act_bytes", n) // 4, device=dev, dtype=torch.float32)
+        ws, wsb = _ws(lib().size("umpr_vgg16_fwd_ws_bytes", n), dev)
+        # the C side takes the full 32-pointer table; the classifier slots are not touched by this stage
+        keep, parr = _ptr_array(params + params[:6])
+        lib().call("umpr_vgg16_features_fwd", images, parr, n, acts, ws, wsb, stream_ptr())
+        off = lib().size("umpr_vgg16_pool5_offset", n) // 4
+        pool5 = acts[off:off + n * 25088].view(n, 25088)
+        ctx.save_for_backward(images, acts, *params)
+        ctx.mark_non_differentiable(acts)
+        return pool5, acts
+
+    @staticmethod
+    def backward(ctx, d_pool5, _):
+        images, acts, *params = ctx.saved_tensors
+        n = images.shape[0]
+        dev = images.device
+        grads = [torch.empty_like(p) for p in params]
+        ws, wsb = _ws(lib().size("umpr_vgg16_features_bwd_ws_bytes", n), dev)
+        keep_p, parr = _ptr_array(params + params[:6])
+        keep_g, garr = _ptr_array(grads + grads[:6])
+        lib().call("umpr_vgg16_features_bwd", images, parr, n, acts, _c(d_pool5), garr, ws, wsb, stream_ptr())
+        return (None, *grads)
+
+
+class _VGGClassifier(torch.autograd.Function):
+    """Linear(25088,4096)-ReLU-Dropout-Linear(4096,4096)-ReLU-Dropout-Linear(4096,1000) on the pooled features."""
+
+    @staticmethod
+    def forward(ctx, pool5, acts, train, masks_in, seed, *params):
+        n = pool5.shape[0]
+        dev = pool5.device
+        params = [_c(p) for p in params]
         use_masks = masks_in is not None
         masks = _c(masks_in) if use_masks else torch.empty(2, n, 4096, device=dev, dtype=torch.uint8)
         out = torch.empty(n, 1000, device=dev, dtype=torch.float32)
         ws, wsb = _ws(lib().size("umpr_vgg16_fwd_ws_bytes", n), dev)
-        keep, parr = _ptr_array(params)
-        lib().call("umpr_vgg16_fwd", images, parr, n, int(train), int(use_masks), int(seed), acts, masks, out, ws, wsb,
-                   stream_ptr())
+        keep, parr = _ptr_array([params[0]] * 26 + params)   # slots 26..31 = classifier
+        lib().call("umpr_vgg16_classifier_fwd", parr, n, int(train), int(use_masks), int(seed), acts, masks, out, ws,
+                   wsb, stream_ptr())
         ctx.dropout = bool(train) or use_masks
-        ctx.save_for_backward(images, acts, masks, *params)
+        ctx.save_for_backward(acts, masks, *params)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        images, acts, masks, *params = ctx.saved_tensors
-        n = images.shape[0]
-        dev = images.device
+        acts, masks, *params = ctx.saved_tensors
+        n = d_out.shape[0]
+        dev = d_out.device
         grads = [torch.empty_like(p) for p in params]
-        ws, wsb = _ws(lib().size("umpr_vgg16_ws_bytes", n), dev)
-        keep_p, parr = _ptr_array(params)
-        keep_g, garr = _ptr_array(grads)
-        lib().call("umpr_vgg16_bwd", images, parr, n, int(ctx.dropout), acts, masks, _c(d_out), garr, ws, wsb,
-                   stream_ptr())
-        return (None, None, None, None, *grads)
+        d_pool5 = torch.empty(n, 25088, device=dev, dtype=torch.float32)
+        ws, wsb = _ws(lib().size("umpr_vgg16_classifier_bwd_ws_bytes", n), dev)
+        keep_p, parr = _ptr_array([params[0]] * 26 + params)
+        keep_g, garr = _ptr_array([grads[0]] * 26 + grads)
+        lib().call("umpr_vgg16_classifier_bwd", parr, n, int(ctx.dropout), acts, masks, _c(d_out), garr, d_pool5, ws,
+                   wsb, stream_ptr())
+        return (d_pool5, None, None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------------------------- K11-K12
@@ -416,7 +449,9 @@ class VGG16(nn.Module):
     def forward(self, images):
         self._calls += 1
         seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
-        return _VGG16.apply(images, self.training, self.dropout_masks, seed, *self.param_list())
+        ps = self.param_list()
+        pool5, acts = _VGGFeatures.apply(images, *ps[:26])
+        return _VGGClassifier.apply(pool5, acts, self.training, self.dropout_masks, seed, *ps[26:])
 
 
 class VisualNet(nn.Module):

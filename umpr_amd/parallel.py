@@ -59,3 +59,45 @@ def allreduce_scalars(values, device):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.tolist()
+
+
+class GradReducer:
+    """Gradient exchange for one training step, overlapped with backward.
+
+    The weight-gradient arena starts with the VGG classifier slice (FusedAdam's ordering).  A post-accumulate hook on
+    fc1.weight - the last classifier gradient autograd produces - launches the all-reduce of that slice asynchronously
+    (RCCL runs on its own stream), so 494 MB of the 554 MB travel over xGMI while the convolutional backward is still
+    computing; `finish()` reduces the remainder and waits.  Sum only: the 1/world scale is folded into the Adam kernel."""
+
+    def __init__(self, opt, n_buckets=4):
+        self.opt = opt
+        self.n_buckets = n_buckets
+        self.handles = []
+        self.early = opt.early_bucket() if hasattr(opt, "early_bucket") else None
+        self.fired = False
+        self.hook = None
+        if self.early is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            self.hook = self.early[3].register_post_accumulate_grad_hook(self._fire)
+
+    def _fire(self, _param=None):
+        arena, lo, hi, _ = self.early
+        for chunk in torch.chunk(arena[lo:hi], self.n_buckets):
+            self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+        self.fired = True
+
+    def finish(self):
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        arenas = self.opt.grad_arenas()
+        if self.fired:
+            arena, lo, hi, _ = self.early
+            rest = [arena[:lo], arena[hi:]] + [a for a in arenas if a.data_ptr() != arena.data_ptr()]
+        else:
+            rest = arenas
+        for a in rest:
+            if a.numel():
+                self.handles.append(dist.all_reduce(a, op=dist.ReduceOp.SUM, async_op=True))
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.fired = False

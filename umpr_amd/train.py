@@ -24,15 +24,19 @@ def evaluate_mse(model, dataloader):
     return se / max(cnt, 1)
 
 
-def train_step(model, opt: FusedAdam, batch, world=1):
-    """model.train(); pred, loss = model(*batch); loss.mean(); zero_grad; backward; step  (main.py:32-37)."""
+def train_step(model, opt: FusedAdam, batch, world=1, reducer=None):
+    """model.train(); pred, loss = model(*batch); loss.mean(); zero_grad; backward; step  (main.py:32-37).
+    With world > 1 the gradients are summed over ranks (RCCL) - by `reducer` overlapped with backward if given."""
     model.train()
     pred, loss = model(*batch)
     loss = loss.mean()
     opt.zero_grad()
     loss.backward()
     if world > 1:
-        parallel.allreduce_arenas(opt.grad_arenas())
+        if reducer is not None:
+            reducer.finish()
+        else:
+            parallel.allreduce_arenas(opt.grad_arenas())
     opt.step(grad_scale=1.0 / world)
     return pred, loss
 
@@ -43,12 +47,13 @@ def training(train_dataloader, valid_dataloader, model, config, model_path, logg
     log(f'Initial validation mse is {valid_mse:.6f}')
     start = time.perf_counter()
     opt = FusedAdam(model, config.learning_rate, config.l2_regularization, config.lr_decay)
+    reducer = parallel.GradReducer(opt) if world > 1 else None
     best_loss, batch_counter = 100, 0
     for epoch in range(config.train_epochs):
         total_loss, total_samples = 0.0, 0
         t0 = time.perf_counter()
         for batch in train_dataloader:
-            pred, loss = train_step(model, opt, batch, world)
+            pred, loss = train_step(model, opt, batch, world, reducer)
             total_loss += loss.item() * len(pred)
             total_samples += len(pred)
             batch_counter += 1
