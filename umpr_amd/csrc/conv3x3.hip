@@ -22,6 +22,8 @@ struct ConvParams {
   const float* mask;  // [N][Cout][H][W] or null: out *= (mask > 0)
   float* y;           // [N][Cout][H][W]
   int N, C, H, W, Cout, relu;
+  long p0_base;  // first flat pixel of this launch (a layer may be covered by a main launch + a finer-tiled tail)
+  long p_end;    // one past the last flat pixel of this launch
 };
 
 template <int BM, int BN>
@@ -39,8 +41,8 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int HW = p.H * p.W;
-  const long NP = (long)p.N * HW;
-  const long p0 = (long)blockIdx.x * BN;
+  const long NP = p.p_end;
+  const long p0 = p.p0_base + (long)blockIdx.x * BN;
   const int m0 = blockIdx.y * BM;
   const int K = p.C * 9;
   const int vecA = (K & 3) == 0;
@@ -220,8 +222,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv3x3_igemm_v2_kern
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
   const int H = p.H, HW = H * W, HP = H + 2;
-  const long NP = (long)p.N * HW;
-  const long p0 = (long)blockIdx.x * BN;
+  const long NP = p.p_end;
+  const long p0 = p.p0_base + (long)blockIdx.x * BN;
   const int m0 = blockIdx.y * BM;
   const int ns = (p.C + CC - 1) / CC;
   const int Kp = ns * KC;
@@ -422,18 +424,38 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// Grid quantisation: a layer is N*H*W/128 x Cout/128 equal workgroups on 512 resident slots (2 per CU); 1568
+// workgroups are 3.06 "rounds", i.e. the last 6% of the work costs a whole round.  So the bulk (a multiple of 512
+// workgroups) runs with 128x128 tiles and the remainder as 128x64 tiles (twice as many, half as long, 3 per CU).
+constexpr int kSlots128 = 512;
 template <int W>
-void launch_v2(const ConvParams& p, int bn, hipStream_t s) {
+void launch_v2(ConvParams p, int bn, hipStream_t s) {
   const long NP = (long)p.N * p.H * p.W;
+  p.p0_base = 0; p.p_end = NP;
   if (p.Cout <= 64) {
     dim3 grid(cdiv(NP, 128), cdiv(p.Cout, 64));
     conv3x3_igemm_v2_kernel<64, 128, W><<<grid, 256, 0, s>>>(p);
-  } else if (bn == 64) {
-    dim3 grid(cdiv(NP, 64), cdiv(p.Cout, 128));
-    conv3x3_igemm_v2_kernel<128, 64, W><<<grid, 256, 0, s>>>(p);
-  } else {
-    dim3 grid(cdiv(NP, 128), cdiv(p.Cout, 128));
-    conv3x3_igemm_v2_kernel<128, 128, W><<<grid, 256, 0, s>>>(p);
+    return;
+  }
+  const int mt = cdiv(p.Cout, 128);
+  const long pt = cdiv(NP, 128);
+  long pt_main = pt;
+  if (bn == 64) pt_main = 0;
+  else if (bn == 0 && pt * mt > kSlots128) {          // auto: peel the partial last round
+    const long full = (pt * mt / kSlots128) * kSlots128;
+    if (pt * mt - full > 0 && pt * mt - full <= kSlots128 * 3 / 4) pt_main = full / mt;
+  }
+  if (pt_main > 0) {
+    ConvParams q = p;
+    q.p_end = pt_main * 128 < NP ? pt_main * 128 : NP;
+    dim3 grid((unsigned)pt_main, mt);
+    conv3x3_igemm_v2_kernel<128, 128, W><<<grid, 256, 0, s>>>(q);
+  }
+  if (pt_main < pt) {
+    ConvParams q = p;
+    q.p0_base = pt_main * 128;
+    dim3 grid(cdiv(NP - q.p0_base, 64), mt);
+    conv3x3_igemm_v2_kernel<128, 64, W><<<grid, 256, 0, s>>>(q);
   }
 }
 
@@ -952,9 +974,9 @@ __global__ void maxpool2_bwd_relu_kernel(const float* __restrict__ x, const floa
 }  // namespace
 
 // ---- internal host entry points ------------------------------------------------------------------------------
-static int g_conv_bn = 128;  // UMPR_CONV_BN=64 selects 128x64 tiles (A/B runs)
+static int g_conv_bn = 0;  // UMPR_CONV_BN: 0 auto (128x128 bulk + 128x64 tail), 128 or 64 force one tile shape (A/B runs)
 static bool g_conv_force_v1 = false;  // UMPR_CONV_V1=1 selects the generic gather kernel (A/B runs)
-static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; const char* q = getenv("UMPR_CONV_BN"); g_conv_bn = q ? atoi(q) : 128; } } g_conv_env_init;
+static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; const char* q = getenv("UMPR_CONV_BN"); g_conv_bn = q ? atoi(q) : 0; } } g_conv_env_init;
 size_t umpr_conv3x3_pack_floats(int Cin, int Cout) {
   const size_t a = (size_t)Cout * ((Cin + V2_CC - 1) / V2_CC) * V2_KC;   // forward pack
   const size_t b = (size_t)Cin * ((Cout + V2_CC - 1) / V2_CC) * V2_KC;   // transposed pack
@@ -979,7 +1001,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
     if (blocks > 4096) blocks = 4096;
     pack_weights_kernel<<<blocks, 256, 0, s>>>(w, wpack, M, C, Cin, transposed);
     UMPR_LAUNCH_CHECK("pack_weights");
-    ConvParams p{x, wpack, bias, mask, y, N, C, H, W, M, relu};
+    ConvParams p{x, wpack, bias, mask, y, N, C, H, W, M, relu, 0, NP};
     UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
     if (W == 224) launch_v2<224>(p, g_conv_bn, s);
     else if (W == 112) launch_v2<112>(p, g_conv_bn, s);
@@ -995,7 +1017,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
     if (int rc = umpr_conv3x3_flip_transpose(w, wpack, Cout, Cin, s)) return rc;
     wm = wpack;
   }
-  ConvParams p{x, wm, bias, mask, y, N, C, H, W, M, relu};
+  ConvParams p{x, wm, bias, mask, y, N, C, H, W, M, relu, 0, NP};
   UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
   if (M <= 64) {
     dim3 grid(cdiv(NP, 128), cdiv(M, 64));
@@ -1017,7 +1039,7 @@ int umpr_conv3x3_flip_transpose(const float* w, float* wt, int Cout, int Cin, hi
   return 0;
 }
 
-constexpr int kWgradTargetWgs = 1024;  // workgroups per wgrad launch (2 resident per CU): split-K factor = this / tiles
+constexpr int kWgradTargetWgs = 512;  // workgroups per wgrad launch (2 resident per CU): split-K factor = this / tiles
 
 // pixel segment = R rows x CW columns with R*CW <= 32: full MFMA k-utilisation when W is a multiple of 32/16/8
 static void wgrad_geometry(int W, int* R, int* CW) {
