@@ -445,3 +445,31 @@ def test_adam_kernel(L, dev):
     check("adam p", pd, pr.float(), atol=1e-6)
     check("adam m", md, mr.float(), atol=1e-7)
     check("adam v", vd, vr.float(), atol=1e-8)
+
+
+def test_train_trajectory_golden(dev):
+    """Three optimiser steps driven like main.py:22-37 (Adam, two groups, coupled L2, ExponentialLR after the first
+    epoch) against the trajectory the reference produced (fixture adam_umpr_r): loss per step and final parameters."""
+    from umpr_amd.config import Config
+    from umpr_amd.model import UMPR
+    from umpr_amd.optim import FusedAdam
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import train_step
+    g = load_golden("adam_umpr_r")
+    P = make_param_state(31, 50, 1000, 1, True, m_scale=0.05)
+    cfg = Config(argv=[])
+    cfg.review_net_only = True
+    model = UMPR(cfg, P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    model = model.to(dev)
+    opt = FusedAdam(model, float(g["lr"]), float(g["l2"]), lr_decay=0.99)
+    for step in range(3):
+        batch = make_batch(500 + step, 4, 1000, review_net_only=True)
+        _, loss = train_step(model, opt, batch)
+        log(f"train step {step}: loss {loss.item():.6f} ref {g['losses'][step]:.6f}")
+        assert abs(loss.item() - g["losses"][step]) < 1e-4
+        if step == 0:
+            opt.epoch_end()
+    for k, p in model.named_parameters():
+        if "param/" + k in g:
+            check("trained " + k, p, g["param/" + k], atol=2e-5, rtol=1e-4)

@@ -222,9 +222,16 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv3x3_igemm_v2_kern
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
   const int H = p.H, HW = H * W, HP = H + 2;
+  // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2).  The Cout/BM workgroups that read
+  // the SAME pixel tile get consecutive slots on one XCD, so the input patch is fetched into that L2 once instead of
+  // once per output-channel tile (FETCH_SIZE showed 2.6x the compulsory bytes with the pixel-major order).
+  const int mt = (p.Cout + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+  const long ptile = (long)(qq / mt) * 8 + xcd;
   const long NP = p.p_end;
-  const long p0 = p.p0_base + (long)blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
+  const long p0 = p.p0_base + ptile * BN;
+  if (p0 >= NP) return;
+  const int m0 = (qq % mt) * BM;
   const int ns = (p.C + CC - 1) / CC;
   const int Kp = ns * KC;
   const int n0 = (int)(p0 / HW);
@@ -433,7 +440,8 @@ void launch_v2(ConvParams p, int bn, hipStream_t s) {
   const long NP = (long)p.N * p.H * p.W;
   p.p0_base = 0; p.p_end = NP;
   if (p.Cout <= 64) {
-    dim3 grid(cdiv(NP, 128), cdiv(p.Cout, 64));
+    const long ptiles = cdiv(NP, 128);
+    dim3 grid((unsigned)(cdiv(ptiles, 8) * 8 * cdiv(p.Cout, 64)));
     conv3x3_igemm_v2_kernel<64, 128, W><<<grid, 256, 0, s>>>(p);
     return;
   }
@@ -448,13 +456,13 @@ void launch_v2(ConvParams p, int bn, hipStream_t s) {
   if (pt_main > 0) {
     ConvParams q = p;
     q.p_end = pt_main * 128 < NP ? pt_main * 128 : NP;
-    dim3 grid((unsigned)pt_main, mt);
+    dim3 grid((unsigned)(cdiv(pt_main, 8) * 8 * mt));
     conv3x3_igemm_v2_kernel<128, 128, W><<<grid, 256, 0, s>>>(q);
   }
   if (pt_main < pt) {
     ConvParams q = p;
     q.p0_base = pt_main * 128;
-    dim3 grid(cdiv(NP - q.p0_base, 64), mt);
+    dim3 grid((unsigned)(cdiv(cdiv(NP - q.p0_base, 64), 8) * 8 * mt));
     conv3x3_igemm_v2_kernel<128, 64, W><<<grid, 256, 0, s>>>(q);
   }
 }
