@@ -4,10 +4,11 @@
     python main.py --data_dir synthetic --batch_size 64                       # single MI355X
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 main.py --data_dir synthetic
 
-The model / optimiser / train / evaluate drivers are the MI355X-native ones (umpr_amd).  Data: the reference's CSV +
-GloVe + JPEG pipeline (src/dataset.py, src/word2vec.py) is the next scope row; until it lands,
-`--data_dir synthetic` (or a data_dir without train.csv) trains on synthetic batches of exactly the layout
-`batch_loader` produces (src/dataset.py:173-182), which is what the throughput numbers are quoted on.
+The model / optimiser / train / evaluate drivers are the MI355X-native ones (umpr_amd).  With a data_dir that holds
+train.csv / valid.csv / test.csv / photos.json (the reference's layout, readme.md:41-60) the CSV + GloVe + JPEG
+pipeline of umpr_amd/data.py feeds them; `--data_dir synthetic` trains on synthetic batches of exactly the layout
+`batch_loader` produces (src/dataset.py:173-182), which is what the throughput numbers are quoted on.  Multi-GPU: every
+rank collates the same global batch and keeps its contiguous chunk (DataParallel's scatter, main.py:82).
 """
 import os
 import sys
@@ -40,6 +41,48 @@ class SyntheticLoader:
         return len(self.batches)
 
 
+class ShardedLoader:
+    """DataLoader whose batches are cut to this rank's contiguous chunk (DataParallel's scatter)."""
+
+    def __init__(self, loader, rank, world):
+        self.loader, self.rank, self.world = loader, rank, world
+
+    def __iter__(self):
+        for b in self.loader:
+            yield parallel.shard_batch(b, self.rank, self.world) if self.world > 1 else b
+
+    def __len__(self):
+        return len(self.loader)
+
+
+def run_real(config, rank, world, log):
+    """main.py:64-99 of the reference: Word2vec -> Dataset -> DataLoader(collate) -> training -> test."""
+    from torch.utils.data import DataLoader
+    from umpr_amd.data import Dataset, Word2vec, batch_loader
+    d = config.data_dir
+    photo_path, photo_json = os.path.join(d, 'photos'), os.path.join(d, 'photos.json')
+    w2v = Word2vec(config.word2vec_file)
+    collate = lambda x: batch_loader(x, config.review_net_only)
+    model = UMPR(config, w2v.embedding).to(config.device)
+    model_path = config.model_path or f"./model/{os.path.basename(d.strip('/'))}.pt"
+    os.makedirs(os.path.dirname(model_path) or '.', exist_ok=True)
+    logger = None if rank else type('L', (), {'info': staticmethod(log)})
+    if not config.test_only:
+        train_data = Dataset(os.path.join(d, 'train.csv'), photo_json, photo_path, w2v, config)
+        valid_data = Dataset(os.path.join(d, 'valid.csv'), photo_json, photo_path, w2v, config)
+        log(f'Training dataset contains {len(train_data)} samples.')
+        g = torch.Generator().manual_seed(0)  # same shuffle on every rank
+        train_dlr = ShardedLoader(DataLoader(train_data, batch_size=config.batch_size, shuffle=True, generator=g,
+                                             collate_fn=collate), rank, world)
+        valid_dlr = ShardedLoader(DataLoader(valid_data, batch_size=config.batch_size, collate_fn=collate), rank, world)
+        training(train_dlr, valid_dlr, model, config, model_path, logger=logger, world=world, rank=rank)
+    if os.path.exists(model_path):
+        model.load_state_dict(torch.load(model_path, map_location=config.device, weights_only=True))
+    test_data = Dataset(os.path.join(d, 'test.csv'), photo_json, photo_path, w2v, config)
+    test_dlr = ShardedLoader(DataLoader(test_data, batch_size=config.batch_size, collate_fn=collate), rank, world)
+    log(f"Test end, test mse is {evaluate_mse(model, test_dlr):.6f}")
+
+
 def main():
     extra = {"synthetic_batches": 20, "synthetic_vocab": 400003, "synthetic_emb": 50, "vgg_weights": ""}
     for k, v in extra.items():
@@ -54,8 +97,7 @@ def main():
     log(str(config))
     have_csv = os.path.exists(os.path.join(config.data_dir, 'train.csv'))
     if have_csv:
-        sys.exit("CSV/GloVe/JPEG loading (src/dataset.py, src/word2vec.py) is not built yet - see DESIGN.md section 6; "
-                 "run with --data_dir synthetic")
+        return run_real(config, rank, world, log)
     g = torch.Generator().manual_seed(0)
     emb = torch.randn(config.synthetic_vocab, config.synthetic_emb, generator=g) * 0.4
     emb[:3] = 0

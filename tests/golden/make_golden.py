@@ -3,7 +3,8 @@
 
 Run:  python tests/golden/make_golden.py        (needs /root/reference; never runs on the GPU box)
 
-What is imported: /root/reference/src/model.py (and nothing else of the reference).  Its top-level
+What is imported: /root/reference/src/model.py, and for the input-pipeline fixtures (gen_dataset) src/dataset.py and
+src/word2vec.py with empty module objects named cv2 / gensim (never called).  model.py's top-level
 ``import torchvision`` cannot be satisfied in this image (torchvision is not installed), so a module object
 named ``torchvision`` is placed in sys.modules first.  For every text-path fixture (ImprovedRnn, RNet, SNet,
 CNet, ControlNet, ReviewNet, UMPR-R) that object is never called - all arithmetic is the reference's code on
@@ -289,11 +290,93 @@ def gen_dataparallel(refmodel):
     save("dp_shards", out)
 
 
+def write_tiny_corpus(root, seed=7):
+    """A small CSV / GloVe / photos.json set that exercises every filter of src/dataset.py (short sentences, empty
+    reviews, too few sentences, truncation to max counts, items without photos, fewer photos than photo_count)."""
+    import json
+    import random
+    rnd = random.Random(seed)
+    os.makedirs(root, exist_ok=True)
+    words = ["w%d" % i for i in range(60)]
+    with open(os.path.join(root, "glove.txt"), "w") as f:
+        for i, w in enumerate(words[:50]):      # w50..w59 are out of vocabulary -> <UNK>
+            f.write(w + " " + " ".join("%.4f" % rnd.uniform(-1, 1) for _ in range(8)) + "\n")
+    rows = []
+    n_users, n_items = 16, 8
+    for u in range(n_users):
+        for it in rnd.sample(range(n_items), rnd.randint(3, 6)):
+            n_sent = rnd.choice([0, 1, 2, 3, 3, 4, 4, 6, 8])
+            sents = []
+            for _ in range(n_sent):
+                L = rnd.choice([2, 4, 6, 6, 7, 8, 9, 12, 25])
+                toks = [rnd.choice(words) if rnd.random() > 0.1 else str(rnd.randint(0, 99)) for _ in range(L)]
+                sents.append(" ".join(toks))
+            review = " . ".join(sents) + (" ." if sents else "")
+            rows.append(dict(userID="U%d" % u, itemID="I%d" % it, review=review, rating=float(rnd.randint(1, 5)),
+                             user_num=u, item_num=it))
+    import pandas as pd
+    pd.DataFrame(rows).to_csv(os.path.join(root, "train.csv"), index=False)
+    with open(os.path.join(root, "photos.json"), "w") as f:
+        for it in range(n_items):
+            if it == 3:
+                continue                         # item without photos: its samples are dropped
+            for k in range(rnd.randint(1, 3)):
+                f.write(json.dumps(dict(business_id="I%d" % it, photo_id="p%d_%d" % (it, k),
+                                        label=rnd.choice(["food", "inside"]))) + "\n")
+    return root
+
+
+class DataCfg:
+    max_sent_count = 6
+    min_sent_count = 2
+    max_ui_sent_count = 3
+    max_sent_length = 10
+    photo_count = 2
+    views = ["food"]
+    review_level = "sentence"
+
+
+def gen_dataset():
+    """Dataset / Word2vec / collate fixtures from the reference's own src/dataset.py and src/word2vec.py (imported with
+    empty module objects named cv2 and gensim - neither is called: photos are ignored in the collate fixture)."""
+    import json
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.modules.setdefault("gensim", types.ModuleType("gensim"))
+    from src.dataset import Dataset, batch_loader, pad_reviews
+    from src.word2vec import Word2vec
+    root = write_tiny_corpus(os.path.join(HERE, "tiny_corpus"))
+    w2v = Word2vec(os.path.join(root, "glove.txt"))
+    out = {}
+    probe = ["w1 w2. w3 77 w55", "  w9 w9 w9 ", "12 w0 w59 w3 w4 w5 w6 w7"]
+    out["sent2indices"] = [w2v.sent2indices(p) for p in probe] + [w2v.sent2indices(probe[2], 5), w2v.sent2indices(probe[1], 6)]
+    out["embedding_rows"] = [list(map(float, w2v.embedding[i])) for i in (0, 1, 2, 3, 52)]
+    out["vocab_len"] = len(w2v)
+    for name, views, level in (("amazon", ["food"], "sentence"), ("two_views", ["food", "inside"], "sentence"),
+                               ("review_level", ["food"], "review")):
+        cfg = DataCfg()
+        cfg.views = views
+        cfg.review_level = level
+        ds = Dataset(os.path.join(root, "train.csv"), os.path.join(root, "photos.json"), os.path.join(root, "photos"), w2v, cfg)
+        out["dataset/" + name] = [list(x) for x in ds.data]
+        out["retain/" + name] = [bool(b) for b in ds.retain_idx]
+        if len(ds) >= 3:
+            b = batch_loader([ds[i] for i in range(min(4, len(ds)))], ignore_photos=True)
+            out["batch/" + name] = [t.tolist() for t in b]
+    out["pad_reviews"] = pad_reviews([[[1, 2, 3], []], [[4]]])
+    with open(os.path.join(HERE, "dataset_golden.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote dataset_golden.json", os.path.getsize(os.path.join(HERE, "dataset_golden.json")) // 1024, "KB")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     _install_import_shims()
     from src import model as refmodel  # the reference's own code
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        gen_dataset()
+        return
+    gen_dataset()
     gen_improved_rnn(refmodel)
     gen_umpr(refmodel, "umpr_r_B4", B=4, n_views=1, review_net_only=True, m_scale=1.0, pseed=21, bseed=22)
     gen_umpr(refmodel, "umpr_r_B4_soft", B=4, n_views=1, review_net_only=True, m_scale=0.05, pseed=23, bseed=24)

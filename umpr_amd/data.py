@@ -1,0 +1,204 @@
+"""Host-side input pipeline with the reference's semantics.
+
+* ``Word2vec``  - GloVe text -> vocabulary + matrix; ids 0/1/2 = <PAD>/<UNK>/<NUM>, all three zero vectors
+  (src/word2vec.py:6-36,46-52).  Only the 'glove' source is supported (gensim is not installed).
+* ``Dataset``   - CSV -> per-sample (user sentences without the target review, item sentences, ui sentences, photo
+  paths, rating) with the reference's filters (src/dataset.py:11-119): sentences of <= 5 tokens dropped, reviews
+  without sentences dropped, min/max sentence counts with longest-first *stable* truncation, target review excluded
+  from the user/item pools, samples whose item lacks a photo for some view dropped.
+* ``pad_reviews`` / ``batch_loader`` - the collate that produces the 8-tensor batch ``UMPR.forward`` consumes
+  (src/dataset.py:122-182): batch-wide common (count, length) for user and item, independent padding for ui, pad id 0,
+  empty sentences get length 1.
+* ``get_image`` - JPEG -> float32 CHW RGB in [0,1], 224x224 (src/dataset.py:134-143).  The reference decodes with
+  cv2 (INTER_LINEAR resize); cv2 is not installed here, PIL's bilinear resize is used instead - pixel values can
+  differ in the last bits from cv2's ("parity unpinned" for the resize; unreadable files become zeros like the
+  reference).
+
+Everything here runs on the host; tensors come out in the layout the kernels expect.
+"""
+from __future__ import annotations
+
+import os
+from collections import defaultdict
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pandas as pd
+import torch
+
+PAD, UNK, NUM = '<PAD>', '<UNK>', '<NUM>'
+
+
+class Word2vec:
+    def __init__(self, emb_path, source='glove', vocab_size=0):
+        if source != 'glove':
+            raise NotImplementedError("only GloVe text files are supported (gensim is not available)")
+        self.padding, self.unknown, self.number = PAD, UNK, NUM
+        self.vocab = [PAD, UNK, NUM]
+        self.word2index = {PAD: 0, UNK: 1, NUM: 2}
+        rows = []
+        with open(emb_path, encoding='utf-8') as f:
+            for line in f:
+                tokens = line.split()
+                if not tokens:
+                    continue
+                self.vocab.append(tokens[0])
+                self.word2index[tokens[0]] = len(self.word2index)  # duplicates keep the later id, as the reference does
+                rows.append(np.asarray(tokens[1:], dtype=np.float64))
+        dim = len(rows[0])
+        self.embedding = np.zeros((3 + len(rows), dim), dtype=np.float64)  # rows 0..2 stay zero
+        self.embedding[3:] = np.stack(rows)
+        self.word_dim = dim
+
+    def sent2indices(self, sentence, align_length=0):
+        indices = []
+        for w in sentence.replace('.', ' ').strip().split():
+            if w.isdigit():
+                indices.append(2)
+            else:
+                indices.append(self.word2index.get(w, 1))
+            if 0 < align_length <= len(indices):
+                break
+        if 0 < align_length and len(indices) < align_length:
+            indices += [0] * (align_length - len(indices))
+        return indices
+
+    def pad(self, sequence, pad_length):
+        return (sequence + [0] * (pad_length - len(sequence)))[:pad_length]
+
+    def __len__(self):
+        return len(self.embedding)
+
+
+class Dataset(torch.utils.data.Dataset):
+    def __init__(self, data_path, photo_json, photo_dir, word2vec, config):
+        self.max_s_count = config.max_sent_count
+        self.min_s_count = config.min_sent_count
+        self.max_ui_s_count = config.max_ui_sent_count
+        self.max_s_length = config.max_sent_length
+        self.photo_count = config.photo_count
+        self.views = config.views
+        df = pd.read_csv(data_path)
+        by_sentence = config.review_level == 'sentence'
+
+        def to_sentences(text):
+            parts = str(text).strip('. ').split('.') if by_sentence else [str(text)]
+            sents = [word2vec.sent2indices(s)[: self.max_s_length] for s in parts]
+            return [s for s in sents if len(s) > 5]
+
+        reviews = [to_sentences(x) for x in df['review']]
+        keep = [len(r) > 0 for r in reviews]
+        photos = self._photo_paths(photo_json, photo_dir, list(df['itemID']), keep)
+        users = self._pool(list(df['user_num']), list(df['item_num']), reviews, keep)
+        items = self._pool(list(df['item_num']), list(df['user_num']), reviews, keep)
+        uis = []
+        for i, sents in enumerate(reviews):
+            if not keep[i]:
+                uis.append(None)
+                continue
+            if len(sents) > self.max_ui_s_count:
+                sents.sort(key=lambda x: -len(x))  # in place, like the reference: later pools see the sorted list
+                sents = sents[: self.max_ui_s_count]
+            uis.append(sents)
+        self.retain_idx = keep
+        ratings = list(df['rating'])
+        sel = [i for i, k in enumerate(keep) if k]
+        self.data = ([users[i] for i in sel], [items[i] for i in sel], [uis[i] for i in sel],
+                     [photos[i] for i in sel], [ratings[i] for i in sel])
+
+    def __getitem__(self, idx):
+        return tuple(x[idx] for x in self.data)
+
+    def __len__(self):
+        return len(self.data[0])
+
+    def _pool(self, lead, costar, reviews, keep):
+        """Sentences of every review the lead (user or item) wrote/received except the one about `costar`."""
+        groups = defaultdict(list)
+        for l, c, r in zip(lead, costar, reviews):
+            groups[l].append((c, r))
+        out = []
+        for i, (l, c) in enumerate(zip(lead, costar)):
+            if not keep[i]:
+                out.append(None)
+                continue
+            sents = [s for cid, r in groups[l] if cid != c for s in r]
+            if len(sents) < self.min_s_count:
+                keep[i] = False
+                out.append(None)
+                continue
+            if len(sents) > self.max_s_count:
+                sents.sort(key=lambda x: -len(x))  # stable, longest first
+                sents = sents[: self.max_s_count]
+            out.append(sents)
+        return out
+
+    def _photo_paths(self, photos_json, photo_dir, item_ids, keep):
+        photo_df = pd.read_json(photos_json, orient='records', lines=True)
+        if 'label' not in photo_df.columns:
+            photo_df['label'] = self.views[0]  # Amazon photos carry no view label
+        groups = defaultdict(dict)
+        for bid, pid, label in zip(photo_df['business_id'], photo_df['photo_id'], photo_df['label']):
+            if label in self.views:
+                groups[bid].setdefault(label, []).append(pid)
+        out = []
+        for i, bid in enumerate(item_ids):
+            if not keep[i]:
+                out.append(None)
+                continue
+            per_view = []
+            for label in self.views:
+                pids = groups[bid].get(label, [])
+                if len(pids) < 1:
+                    keep[i] = False
+                    per_view = None
+                    break
+                paths = [os.path.join(photo_dir, str(p) + '.jpg') for p in pids[: self.photo_count]]
+                paths += ['unknown'] * (self.photo_count - len(paths))
+                per_view.append(paths)
+            out.append(per_view)
+        return out
+
+
+def pad_reviews(reviews, max_count=None, max_len=None, pad=0):
+    if max_count is None:
+        max_count = max(len(r) for r in reviews)
+    reviews = [sents + [[]] * (max_count - len(sents)) for sents in reviews]
+    lengths = [[max(1, len(s)) for s in sents] for sents in reviews]
+    if max_len is None:
+        max_len = max(max(l) for l in lengths)
+    padded = [[s + [pad] * (max_len - len(s)) for s in sents] for sents in reviews]
+    return padded, lengths
+
+
+def get_image(path, resize=(224, 224)):
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            im = im.convert('RGB').resize(resize, Image.BILINEAR)
+            a = np.asarray(im, dtype=np.float64).transpose(2, 0, 1) / 255.0
+        return a
+    except Exception:
+        return np.zeros([3] + list(resize))
+
+
+def batch_loader(batch_list, ignore_photos=False, photo_size=(224, 224), pad=0):
+    users = [s[0] for s in batch_list]
+    items = [s[1] for s in batch_list]
+    uis = [s[2] for s in batch_list]
+    ratings = [s[4] for s in batch_list]
+    photos = []
+    if not ignore_photos:
+        paths = [p for s in batch_list for view in s[3] for p in view]
+        with ThreadPoolExecutor() as pool:
+            imgs = iter(list(pool.map(lambda x: get_image(x, photo_size), paths)))
+        photos = [[[next(imgs) for _ in view] for view in s[3]] for s in batch_list]
+    max_count = max(max(len(u), len(i)) for u, i in zip(users, items))
+    max_len = max(max(max(len(s) for s in u), max(len(s) for s in i)) for u, i in zip(users, items))
+    pu, lu = pad_reviews(users, max_count, max_len, pad)
+    pi, li = pad_reviews(items, max_count, max_len, pad)
+    pui, lui = pad_reviews(uis, pad=pad)
+    return (torch.LongTensor(pu), torch.LongTensor(pi), torch.LongTensor(pui), torch.LongTensor(lu),
+            torch.LongTensor(li), torch.LongTensor(lui),
+            torch.from_numpy(np.asarray(photos, dtype=np.float32)) if photos else torch.Tensor([]),
+            torch.Tensor(ratings))
