@@ -181,6 +181,10 @@ int umpr_head_bwd(const float* rr, const float* c_u, const float* c_i, const flo
 int umpr_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, long step, double grad_scale, void* stream);
 
+/* ---- test aid: fills the LDS of every CU with NaN (LDS is not cleared between kernels, so a kernel that reads LDS
+ * it never wrote shows up as NaN in the parity tests instead of passing by luck).  sink: one int of device memory. */
+int umpr_debug_poison_lds(void* sink, void* stream);
+
 /* ---- kernel timing for bench.py's roofline line: while enabled, the library brackets every launch of a kernel
  * family with HIP events on the launch stream.  family: 0 conv3x3 implicit GEMM (fwd+dgrad), 1 conv3x3 wgrad,
  * 2 generic GEMM, 3 GRU.  read() synchronises the recorded events and returns totals since reset():

@@ -59,6 +59,15 @@ def st():
     return torch.cuda.current_stream().cuda_stream
 
 
+@pytest.fixture(autouse=True)
+def poison_lds(L, dev):
+    """LDS keeps the previous kernel's bytes: poison it with NaN before every test so that a read of never-written
+    LDS (0 * NaN) fails deterministically instead of once in a while."""
+    sink = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.call("umpr_debug_poison_lds", sink, st())
+    yield
+
+
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K,ta,tb", [
     (128, 128, 64, 0, 0), (200, 150, 50, 0, 1), (64, 384, 27, 1, 0), (130, 70, 1000, 1, 1), (32, 32, 2, 0, 0),

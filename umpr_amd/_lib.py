@@ -64,6 +64,7 @@ SIGNATURES = {
     "umpr_head_fwd": ("pppppppppppppfiiipppppppp", "i"),
     "umpr_head_bwd": ("pppppppppppfiiippppppppppppppppppppp", "i"),
     "umpr_adam_step": ("ppppldddddldp", "i"),
+    "umpr_debug_poison_lds": ("pp", "i"),
     "umpr_profile_enable": ("i", "i"),
     "umpr_profile_reset": ("", "i"),
     "umpr_profile_read": ("ippp", "i"),

@@ -501,6 +501,21 @@ int umpr_head_bwd(const float* rr, const float* c_u, const float* c_i, const flo
   return umpr_head_launch(h, 1, S(stream));
 }
 
+// ------------------------------------------------------------------------------------------------ debug
+namespace {
+__global__ void poison_lds_kernel(int* sink) {
+  __shared__ float s[163840 / 4];  // all 160 KiB of the CU
+  for (int e = threadIdx.x; e < 163840 / 4; e += blockDim.x) s[e] = __int_as_float(0x7fc00000);  // quiet NaN
+  __syncthreads();
+  if (s[(threadIdx.x * 97) % (163840 / 4)] == 0.f) sink[0] = 1;  // keep the stores alive
+}
+}  // namespace
+int umpr_debug_poison_lds(void* sink, void* stream) {
+  poison_lds_kernel<<<1024, 256, 0, S(stream)>>>(static_cast<int*>(sink));
+  UMPR_LAUNCH_CHECK("poison_lds");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ profiling
 int umpr_profile_enable(int on) { g_prof_on = on != 0; return 0; }
 int umpr_profile_reset(void) {
