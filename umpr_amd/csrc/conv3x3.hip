@@ -440,6 +440,14 @@ void launch_v2(ConvParams p, int bn, hipStream_t s) {
   const long NP = (long)p.N * p.H * p.W;
   p.p0_base = 0; p.p_end = NP;
   if (p.Cout <= 64) {
+    // 64 output channels: a 64 x 256-pixel tile gives each wave the same 72 MFMAs per stage as the 128x128 tile
+    // (the 64x128 tile has half the MFMAs per staged byte and ran at ~90 instead of ~110 TFLOP/s)
+    if (W >= 224 && bn != 128 && bn != 64) {
+      const long ptiles = cdiv(NP, 256);
+      dim3 grid((unsigned)(cdiv(ptiles, 8) * 8 * cdiv(p.Cout, 64)));
+      conv3x3_igemm_v2_kernel<64, 256, W><<<grid, 256, 0, s>>>(p);
+      return;
+    }
     const long ptiles = cdiv(NP, 128);
     dim3 grid((unsigned)(cdiv(ptiles, 8) * 8 * cdiv(p.Cout, 64)));
     conv3x3_igemm_v2_kernel<64, 128, W><<<grid, 256, 0, s>>>(p);

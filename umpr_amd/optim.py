@@ -77,6 +77,30 @@ class FusedAdam:
         """ExponentialLR.step() (main.py:54)."""
         self.lr *= self.lr_decay
 
+    def state_dict(self):
+        """Adam moments per parameter NAME (independent of the arena order), step count and current learning rate."""
+        st = {"step": self.step_count, "lr": float(self.lr), "base_lr": float(self.base_lr), "m": {}, "v": {}}
+        for g in self.groups:
+            for n in g.names:
+                off, k = g.offsets[n]
+                st["m"][n] = g.m[off:off + k].detach().cpu().clone()
+                st["v"][n] = g.v[off:off + k].detach().cpu().clone()
+        return st
+
+    def load_state_dict(self, st):
+        self.step_count = int(st["step"])
+        self.lr = float(st["lr"])
+        self.base_lr = float(st.get("base_lr", self.base_lr))
+        for g in self.groups:
+            for n in g.names:
+                off, k = g.offsets[n]
+                g.m[off:off + k].copy_(st["m"][n])
+                g.v[off:off + k].copy_(st["v"][n])
+
+    def reattach(self):
+        """No-op hook: ``model.load_state_dict`` copies INTO the arena views, so parameters stay attached."""
+        return None
+
     def grad_arenas(self):
         return [g.g for g in self.groups if g.numel]
 

@@ -6,6 +6,7 @@ import time
 import torch
 
 from . import parallel
+from .checkpoint import load_checkpoint, save_checkpoint
 from .optim import FusedAdam
 
 
@@ -48,8 +49,14 @@ def training(train_dataloader, valid_dataloader, model, config, model_path, logg
     start = time.perf_counter()
     opt = FusedAdam(model, config.learning_rate, config.l2_regularization, config.lr_decay)
     reducer = parallel.GradReducer(opt) if world > 1 else None
-    best_loss, batch_counter = 100, 0
-    for epoch in range(config.train_epochs):
+    best_loss, batch_counter, first_epoch = 100, 0, 0
+    resume = getattr(config, "resume", "")
+    if resume:  # not in the reference (it keeps no optimiser / epoch state): exact resume from umpr_amd.checkpoint
+        meta = load_checkpoint(resume, model, opt, map_location=next(model.parameters()).device)
+        first_epoch, batch_counter = meta.get("epoch", 0), meta.get("batch_counter", 0)
+        best_loss = meta.get("best_loss", best_loss)
+        log(f'Resumed from {resume}: epoch {first_epoch}, batch {batch_counter}')
+    for epoch in range(first_epoch, config.train_epochs):
         total_loss, total_samples = 0.0, 0
         t0 = time.perf_counter()
         for batch in train_dataloader:
@@ -61,9 +68,10 @@ def training(train_dataloader, valid_dataloader, model, config, model_path, logg
                 valid_mse = evaluate_mse(model, valid_dataloader)
                 log(f'Epoch {epoch:2d}; batch {batch_counter:5d}; train loss {total_loss / total_samples:.6f}; '
                     f'valid mse {valid_mse:.6f}')
-                if best_loss > valid_mse and rank == 0:
-                    torch.save(model.state_dict(), model_path)
+                if best_loss > valid_mse:
                     best_loss = valid_mse
+                    if rank == 0:
+                        save_checkpoint(model_path, model, opt, epoch, batch_counter, best_loss)
         opt.epoch_end()
         dt = time.perf_counter() - t0
         log(f'Epoch {epoch:3d} done; train loss {total_loss / max(total_samples, 1):.6f}; '
