@@ -482,3 +482,70 @@ def test_train_trajectory_golden(dev):
     for k, p in model.named_parameters():
         if "param/" + k in g:
             check("trained " + k, p, g["param/" + k], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,seed", [(1, 3), (3, 4)])
+def test_umpr_r_small_batches_vs_oracle(dev, B, seed):
+    """Edge cases the fixtures do not hold: a single sample (fewer sequences than one 64-row GRU tile), ragged lengths,
+    and a batch where every sentence but one is an empty (length-1, id 0) pad."""
+    from oracle import umpr_ref as R
+    from umpr_amd.config import Config
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_batch, make_param_state
+    P = make_param_state(61, 50, 800, 1, True, m_scale=0.05)
+    batch = list(make_batch(seed, B, 800, review_net_only=True))
+    if B == 3:  # blank out sample 1: all sentences empty except the first
+        for ids, lens in ((batch[0], batch[3]), (batch[1], batch[4])):
+            ids[1, 1:] = 0
+            lens[1, 1:] = 1
+    cfg = Config(argv=[])
+    cfg.review_net_only = True
+    model = UMPR(cfg, P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    pred, loss = model(*batch)
+    loss.backward()
+    for k, p in P.items():
+        if k != "embedding.weight":
+            p.requires_grad_(True)
+    rp, rl = R.umpr_forward(P, tuple(batch), review_net_only=True, aten=True)
+    rl.backward()
+    check(f"small-batch pred B{B}", pred, rp, atol=1e-4)
+    check(f"small-batch loss B{B}", loss, rl, atol=1e-4)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            check(f"small-batch grad {k} B{B}", p.grad, P[k].grad, atol=1e-6, rel_to_max=2e-3)
+
+
+def test_full_size_properties(L, dev):
+    """BASELINE.json sizes (64 images, 1280 sequences): properties that need no CPU reference.
+    (1) the VGG16 output of an image does not depend on the batch it is in - bit for bit (tiles straddle images, the
+        accumulation order per output pixel is fixed); (2) two runs are bitwise identical (no atomics on the path);
+    (3) a GRU sequence's output does not depend on which other sequences share its 64-row tile."""
+    from umpr_amd.model import UMPR, VGG16, _EmbedGru
+    g = torch.Generator().manual_seed(5)
+    vgg = VGG16().to(dev).eval()
+    x = torch.rand(64, 3, 224, 224, generator=g).to(dev)
+    with torch.no_grad():
+        full = vgg(x)
+        again = vgg(x)
+        part = vgg(x[5:7].contiguous())
+    assert torch.isfinite(full).all()
+    assert torch.equal(full, again), "VGG16 forward is not run-to-run deterministic"
+    assert torch.equal(full[5:7], part), "VGG16 output of an image depends on its batch"
+    N, Lm, E = 1280, 20, 50
+    emb = (torch.randn(5000, E, generator=g) * 0.4).to(dev)
+    ids = torch.randint(3, 5000, (N, Lm), generator=g)
+    lengths = torch.randint(1, Lm + 1, (N,), generator=g)
+    w = [((torch.rand(s, generator=g) * 2 - 1) / 8).to(dev) for _ in range(2) for s in ((192, E), (192, 64), (192,), (192,))]
+    lens, order = UMPR._host_perm(lengths, dev)
+    ident = torch.arange(N, dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        out_sorted = _EmbedGru.apply(ids.to(dev), lens, order, emb, *w)      # tiles grouped by length, permuted rows
+    out_ident = torch.empty(N, Lm, 128, device=dev)
+    wsb = L.size("umpr_embed_gru_bidir_ws_bytes", N, Lm, E)
+    ws = torch.empty(wsb // 4 + 64, device=dev)
+    L.call("umpr_embed_gru_bidir_fwd", ids.to(dev), emb, E, *w, lens, ident, ident, N, Lm, out_ident, None, ws,
+           ws.numel() * 4, st())                                             # natural grouping, no permutation
+    # out_sorted[order[n]] is sequence n (dst_row = sorted_indices); compare with the unpermuted run bit for bit
+    assert torch.equal(out_sorted[order.long()], out_ident), "GRU output depends on tile grouping"
