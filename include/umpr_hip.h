@@ -148,13 +148,14 @@ size_t umpr_vgg16_features_bwd_ws_bytes(int n_img);
 int umpr_vgg16_features_bwd(const float* images, const float* const* params, int n_img, const float* acts,
                             const float* d_pool5, float* const* grads, float* ws, size_t ws_bytes, void* stream);
 /* per-layer entry points (also what the composite calls) */
-/* wpack / wt: scratch of umpr_conv3x3_pack_bytes(Cin, Cout) - the kernels read the weights in a packed order */
-size_t umpr_conv3x3_pack_bytes(int Cin, int Cout);
+/* wpack / wt: scratch of umpr_conv3x3_pack_bytes(...) - packed weights, or on the 56/28/14 maps the Winograd
+ * F(2x2,3x3) buffers (with a smaller scratch those layers fall back to the direct kernel) */
+size_t umpr_conv3x3_pack_bytes(int N, int Cin, int Cout, int H, int W);
 int umpr_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
-                     int Cout, int relu, float* wpack, void* stream);
+                     int Cout, int relu, float* wpack, size_t wpack_bytes, void* stream);
 /* dx = conv_transpose(dy, w) [* (mask_src > 0)] */
 int umpr_conv3x3_bwd_data(const float* dy, const float* w, const float* mask_src /*or NULL*/, float* dx, int N,
-                          int Cin, int H, int W, int Cout, float* wt, void* stream);
+                          int Cin, int H, int W, int Cout, float* wt, size_t wt_bytes, void* stream);
 size_t umpr_conv3x3_bwd_weight_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int umpr_conv3x3_bwd_weight(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                             int Cout, float* ws, size_t ws_bytes, void* stream);

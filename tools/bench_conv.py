@@ -42,14 +42,15 @@ def main():
         y = torch.empty(n, co, hw, hw, device=dev)
         gy = torch.randn(n, co, hw, hw, device=dev)
         dx = torch.empty_like(x)
-        wt = torch.empty(L.size("umpr_conv3x3_pack_bytes", ci, co) // 4, device=dev)
+        wt = torch.empty(L.size("umpr_conv3x3_pack_bytes", n, ci, co, hw, hw) // 4, device=dev)
+        wtb = wt.numel() * 4
         dw, db = torch.empty_like(w), torch.empty_like(b)
         wsb = L.size("umpr_conv3x3_bwd_weight_ws_bytes", n, ci, co, hw, hw)
         ws = torch.empty(wsb // 4 + 64, device=dev)
         fl = 2.0 * n * hw * hw * co * ci * 9
         res = []
-        for name, fn in (("fwd", lambda: L.call("umpr_conv3x3_fwd", x, w, b, y, n, ci, hw, hw, co, 1, wt, st)),
-                         ("dgrad", lambda: L.call("umpr_conv3x3_bwd_data", gy, w, x, dx, n, ci, hw, hw, co, wt, st)),
+        for name, fn in (("fwd", lambda: L.call("umpr_conv3x3_fwd", x, w, b, y, n, ci, hw, hw, co, 1, wt, wtb, st)),
+                         ("dgrad", lambda: L.call("umpr_conv3x3_bwd_data", gy, w, x, dx, n, ci, hw, hw, co, wt, wtb, st)),
                          ("wgrad", lambda: L.call("umpr_conv3x3_bwd_weight", gy, x, dw, db, n, ci, hw, hw, co, ws, ws.numel() * 4, st))):
             if a.only and a.only != name:
                 continue

@@ -54,9 +54,9 @@ SIGNATURES = {
     "umpr_vgg16_classifier_bwd": ("piippppppzp", "i"),
     "umpr_vgg16_features_bwd_ws_bytes": ("i", "z"),
     "umpr_vgg16_features_bwd": ("ppippppzp", "i"),
-    "umpr_conv3x3_pack_bytes": ("ii", "z"),
-    "umpr_conv3x3_fwd": ("ppppiiiiiipp", "i"),
-    "umpr_conv3x3_bwd_data": ("ppppiiiiipp", "i"),
+    "umpr_conv3x3_pack_bytes": ("iiiii", "z"),
+    "umpr_conv3x3_fwd": ("ppppiiiiiipzp", "i"),
+    "umpr_conv3x3_bwd_data": ("ppppiiiiipzp", "i"),
     "umpr_conv3x3_bwd_weight_ws_bytes": ("iiiii", "z"),
     "umpr_conv3x3_bwd_weight": ("ppppiiiiipzp", "i"),
     "umpr_maxpool2_fwd": ("ppliip", "i"),

@@ -270,12 +270,17 @@ size_t vgg_scratch_bytes(int n) {
     const size_t b = umpr_conv3x3_wgrad_ws_bytes(n, L.conv_cin[i], L.conv_cout[i], L.conv_hw[i], L.conv_hw[i]);
     if (b > slab) slab = b;
   }
+  for (int i = 0; i < 13; ++i) {  // packed weights / Winograd buffers of the forward convs share this region
+    const size_t b = umpr_conv3x3_pack_floats(n, L.conv_cin[i], L.conv_cout[i], L.conv_hw[i], L.conv_hw[i]) * sizeof(float);
+    if (b > slab) slab = b;
+  }
   size_t fcs = (size_t)4 * n * 25088;
   if ((size_t)16 * n * 4096 > fcs) fcs = (size_t)16 * n * 4096;
   fcs *= sizeof(float);
   return align_up(slab > fcs ? slab : fcs, 256);
 }
-constexpr size_t kWtFloats = (size_t)512 * 512 * 9 + 4096;  // >= umpr_conv3x3_pack_floats of every VGG layer
+// scratch of the data-gradient convs (packed weights / Winograd buffers): as large as the forward scratch
+static size_t wt_floats(int n) { return vgg_scratch_bytes(n) / sizeof(float); }
 }  // namespace
 
 size_t umpr_vgg16_fwd_ws_bytes(int n_img) { return vgg_scratch_bytes(n_img); }
@@ -283,17 +288,21 @@ size_t umpr_vgg16_fwd_ws_bytes(int n_img) { return vgg_scratch_bytes(n_img); }
 size_t umpr_vgg16_ws_bytes(int n_img) {
   // [d_pool5][gradient ping][gradient pong] (largest activation each) [packed weights][scratch]
   const size_t big = (size_t)n_img * 64 * 224 * 224;
-  return ((size_t)n_img * 25088 + 2 * big + kWtFloats) * sizeof(float) + vgg_scratch_bytes(n_img);
+  return ((size_t)n_img * 25088 + 2 * big + wt_floats(n_img)) * sizeof(float) + vgg_scratch_bytes(n_img);
 }
 
-size_t umpr_conv3x3_pack_bytes(int Cin, int Cout) { return umpr_conv3x3_pack_floats(Cin, Cout) * sizeof(float); }
+size_t umpr_conv3x3_pack_bytes(int N, int Cin, int Cout, int H_, int W) {
+  return umpr_conv3x3_pack_floats(N, Cin, Cout, H_, W) * sizeof(float);
+}
 int umpr_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H_, int W,
-                     int Cout, int relu, float* wpack, void* stream) {
-  return umpr_conv3x3_run(x, w, 0, bias, nullptr, y, N, Cin, Cout, H_, W, relu, wpack, S(stream));
+                     int Cout, int relu, float* wpack, size_t wpack_bytes, void* stream) {
+  return umpr_conv3x3_run(x, w, 0, bias, nullptr, y, N, Cin, Cout, H_, W, relu, wpack, wpack_bytes / sizeof(float),
+                          S(stream));
 }
 int umpr_conv3x3_bwd_data(const float* dy, const float* w, const float* mask_src, float* dx, int N, int Cin, int H_,
-                          int W, int Cout, float* wt, void* stream) {
-  return umpr_conv3x3_run(dy, w, 1, nullptr, mask_src, dx, N, Cin, Cout, H_, W, 0, wt, S(stream));
+                          int W, int Cout, float* wt, size_t wt_bytes, void* stream) {
+  return umpr_conv3x3_run(dy, w, 1, nullptr, mask_src, dx, N, Cin, Cout, H_, W, 0, wt, wt_bytes / sizeof(float),
+                          S(stream));
 }
 size_t umpr_conv3x3_bwd_weight_ws_bytes(int N, int Cin, int Cout, int H_, int W) {
   return umpr_conv3x3_wgrad_ws_bytes(N, Cin, Cout, H_, W);
@@ -324,7 +333,7 @@ int umpr_vgg16_features_fwd(const float* images, const float* const* params, int
       float* y = acts + L.conv_off[ci];
       const int hw = L.conv_hw[ci];
       if (int rc = umpr_conv3x3_run(x, params[2 * ci], 0, params[2 * ci + 1], nullptr, y, n, L.conv_cin[ci],
-                                    L.conv_cout[ci], hw, hw, 1, ws, s)) return rc;
+                                    L.conv_cout[ci], hw, hw, 1, ws, ws_bytes / sizeof(float), s)) return rc;
       x = y;
     }
     const int hw = L.conv_hw[ci - 1];
@@ -410,7 +419,7 @@ int umpr_vgg16_classifier_bwd(const float* const* params, int n, int train, cons
 
 size_t umpr_vgg16_features_bwd_ws_bytes(int n_img) {
   const size_t big = (size_t)n_img * 64 * 224 * 224;
-  return (2 * big + kWtFloats) * sizeof(float) + vgg_scratch_bytes(n_img);
+  return (2 * big + wt_floats(n_img)) * sizeof(float) + vgg_scratch_bytes(n_img);
 }
 
 int umpr_vgg16_features_bwd(const float* images, const float* const* params, int n, const float* acts,
@@ -422,7 +431,7 @@ int umpr_vgg16_features_bwd(const float* images, const float* const* params, int
   float* gA = ws;
   float* gB = ws + big;
   float* wt = gB + big;
-  float* scratch = wt + kWtFloats;
+  float* scratch = wt + wt_floats(n);
   const size_t slab_bytes = vgg_scratch_bytes(n);
   const float* g = d_pool5;
   float* cur = gA; float* oth = gB;
@@ -442,7 +451,8 @@ int umpr_vgg16_features_bwd(const float* images, const float* const* params, int
       if (ci == 0) break;
       // input came straight from a conv+ReLU (j > 0): mask by it; from a pool (j == 0): the pool backward masks
       const float* mask = j > 0 ? xin : nullptr;
-      if (int rc = umpr_conv3x3_run(g, params[2 * ci], 1, nullptr, mask, cur, n, cin, cout, hw, hw, 0, wt, s)) return rc;
+      if (int rc = umpr_conv3x3_run(g, params[2 * ci], 1, nullptr, mask, cur, n, cin, cout, hw, hw, 0, wt, wt_floats(n), s))
+        return rc;
       g = cur; { float* t = cur; cur = oth; oth = t; }
     }
     if (ci == 0 && b == 0) break;

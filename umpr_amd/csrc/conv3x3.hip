@@ -990,29 +990,47 @@ __global__ void maxpool2_bwd_relu_kernel(const float* __restrict__ x, const floa
 }  // namespace
 
 // ---- internal host entry points ------------------------------------------------------------------------------
+static bool g_conv_no_wino = false;  // UMPR_CONV_WINO=0 keeps the deep layers on the direct kernel (A/B runs)
 static int g_conv_bn = 0;  // UMPR_CONV_BN: 0 auto (128x128 bulk + 128x64 tail), 128 or 64 force one tile shape (A/B runs)
 static bool g_conv_force_v1 = false;  // UMPR_CONV_V1=1 selects the generic gather kernel (A/B runs)
-static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; const char* q = getenv("UMPR_CONV_BN"); g_conv_bn = q ? atoi(q) : 0; } } g_conv_env_init;
-size_t umpr_conv3x3_pack_floats(int Cin, int Cout) {
+static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; const char* q = getenv("UMPR_CONV_BN"); g_conv_bn = q ? atoi(q) : 0; const char* wq = getenv("UMPR_CONV_WINO"); g_conv_no_wino = wq && wq[0] == '0'; } } g_conv_env_init;
+static bool wino_layer(int H, int W) { return H == W && (W == 56 || W == 28 || W == 14); }
+
+// scratch floats a conv call needs: the packed weights, or (deep layers) the Winograd U / V / M buffers
+size_t umpr_conv3x3_pack_floats(int N, int Cin, int Cout, int H, int W) {
   const size_t a = (size_t)Cout * ((Cin + V2_CC - 1) / V2_CC) * V2_KC;   // forward pack
   const size_t b = (size_t)Cin * ((Cout + V2_CC - 1) / V2_CC) * V2_KC;   // transposed pack
   const size_t c = (size_t)Cin * Cout * 9;                               // plain flip-transpose (generic kernel)
   size_t m = a > b ? a : b;
-  return m > c ? m : c;
+  if (c > m) m = c;
+  if (wino_layer(H, W) && !g_conv_no_wino) {
+    const size_t f = umpr_wino_ws_floats(N, Cin, Cout, H, W), t = umpr_wino_ws_floats(N, Cout, Cin, H, W);
+    if (f > m) m = f;
+    if (t > m) m = t;
+  }
+  return m;
 }
 
 // Forward (transposed = 0):  y[N][Cout] = relu?(conv(x[N][Cin], w) + bias)
 // Data gradient (transposed = 1):  y[N][Cin] = conv^T(x[N][Cout], w) * [mask > 0]
-// w is always the parameter [Cout][Cin][3][3]; wpack: scratch of umpr_conv3x3_pack_floats(Cin, Cout) floats.
+// w is always the parameter [Cout][Cin][3][3]; wpack: scratch of umpr_conv3x3_pack_floats(...) floats.
 int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
-                     int N, int Cin, int Cout, int H, int W, int relu, float* wpack, hipStream_t s) {
+                     int N, int Cin, int Cout, int H, int W, int relu, float* wpack, size_t wpack_floats,
+                     hipStream_t s) {
   UMPR_REQUIRE(N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3: bad shape");
   const int M = transposed ? Cin : Cout;   // output channels of this launch
   const int C = transposed ? Cout : Cin;   // reduction channels
   const long NP = (long)N * H * W;
+  if (wino_layer(H, W) && !g_conv_no_wino && !g_conv_force_v1 && wpack && C >= 32 &&
+      wpack_floats >= umpr_wino_ws_floats(N, C, M, H, W)) {
+    // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs; timed under the same family with the direct conv's FLOP count
+    UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
+    return umpr_wino_conv3x3(x, w, transposed, bias, mask, y, N, Cin, Cout, H, W, relu, wpack, wpack_floats, s);
+  }
   const bool v2 = H == W && !g_conv_force_v1 && wpack && (W == 224 || W == 112 || W == 56 || W == 28 || W == 14);
   if (v2) {
     const long total = (long)M * ((C + V2_CC - 1) / V2_CC) * V2_KC;
+    UMPR_REQUIRE(wpack_floats >= (size_t)total, "conv3x3: weight scratch too small");
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     pack_weights_kernel<<<blocks, 256, 0, s>>>(w, wpack, M, C, Cin, transposed);
@@ -1029,7 +1047,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
   }
   const float* wm = w;
   if (transposed) {
-    UMPR_REQUIRE(wpack != nullptr, "conv3x3: data gradient needs the weight scratch");
+    UMPR_REQUIRE(wpack != nullptr && wpack_floats >= (size_t)Cin * Cout * 9, "conv3x3: data gradient needs the weight scratch");
     if (int rc = umpr_conv3x3_flip_transpose(w, wpack, Cout, Cin, s)) return rc;
     wm = wpack;
   }

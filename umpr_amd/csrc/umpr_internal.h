@@ -45,9 +45,14 @@ struct UmprHead {
 int umpr_head_launch(const UmprHead& p, int backward, hipStream_t s);
 
 // conv3x3.hip
-size_t umpr_conv3x3_pack_floats(int Cin, int Cout);
+size_t umpr_conv3x3_pack_floats(int N, int Cin, int Cout, int H, int W);
 int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
-                     int N, int Cin, int Cout, int H, int W, int relu, float* wpack, hipStream_t s);
+                     int N, int Cin, int Cout, int H, int W, int relu, float* wpack, size_t wpack_floats,
+                     hipStream_t s);
+// winograd.hip
+size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W);
+int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
+                      int N, int Cin, int Cout, int H, int W, int relu, float* ws, size_t ws_floats, hipStream_t s);
 int umpr_conv3x3_flip_transpose(const float* w, float* wt, int Cout, int Cin, hipStream_t s);
 size_t umpr_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,

@@ -1,0 +1,329 @@
+// Winograd F(2x2,3x3) path for the deep VGG16 layers (56x56, 28x28, 14x14 maps), forward and data gradient, fp32.
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile / 4x4 input tile / channel pair
+//
+// 16 independent GEMMs  M[xi][m][t] = sum_c U[xi][m][c] * V[xi][c][t]  (t = tile index over the batch) replace the
+// 9-tap implicit GEMM: 2.25x fewer MFMA FLOPs.  Three kernels per layer call:
+//   wino_input_kernel  : x -> V   (HBM bound: reads |x|, writes 4|x|)
+//   wino_gemm_kernel   : batched GEMM on v_mfma_f32_32x32x2_f32, same structure as conv3x3_igemm_v2 (LDS double
+//                        buffer, fragment prefetch pinned one step ahead, staging pieces between MFMAs, 2-level
+//                        accumulation, XCD-aware tile order); weights arrive pre-laid-out in the LDS image order
+//   wino_output_kernel : M -> y   with the fused epilogue (+bias, ReLU) or (dgrad) * [mask > 0]
+// plus wino_weights_kernel (U = G g G^T, for dgrad on the flipped, channel-transposed kernel).
+// The shallow layers (224, 112) stay on the direct kernel: there the 16x activation-sized transform traffic costs
+// more than the MFMA time it saves.  Weight gradients stay on the direct wgrad kernel.
+#include "umpr_common.h"
+#include "umpr_internal.h"
+
+namespace {
+
+constexpr int WK = 32;    // channels per GEMM stage
+constexpr int WBM = 128;  // output-channel tile
+constexpr int WBN = 128;  // tile-index tile
+constexpr int WLDA = WBM + 4;
+
+// U[xi][mt][s][k][m_local]  (mt = m / 128, s = c / 32, k = c % 32), zero padded in both m and c
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int M, int C, int CinW,
+                                    int transposed) {
+  const int MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
+  const long total = (long)MT * WBM * S * WK;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ml = (int)(i % WBM);
+    long r = i / WBM;
+    const int k = (int)(r % WK); r /= WK;
+    const int s = (int)(r % S);
+    const int mt = (int)(r / S);
+    const int m = mt * WBM + ml, c = s * WK + k;
+    float g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = 0.f;
+      if (m < M && c < C) v = transposed ? w[((long)c * CinW + m) * 9 + 8 - t] : w[((long)m * CinW + c) * 9 + t];
+      g[t] = v;
+    }
+    // Gg = G g  (4x3), then (G g) G^T (4x4);  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+    float gg[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      gg[0][j] = g[j];
+      gg[1][j] = 0.5f * (g[j] + g[3 + j] + g[6 + j]);
+      gg[2][j] = 0.5f * (g[j] - g[3 + j] + g[6 + j]);
+      gg[3][j] = g[6 + j];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float u0 = gg[a][0], u1 = 0.5f * (gg[a][0] + gg[a][1] + gg[a][2]),
+                  u2 = 0.5f * (gg[a][0] - gg[a][1] + gg[a][2]), u3 = gg[a][2];
+      const long per = total;
+      U[(long)(a * 4 + 0) * per + i] = u0;
+      U[(long)(a * 4 + 1) * per + i] = u1;
+      U[(long)(a * 4 + 2) * per + i] = u2;
+      U[(long)(a * 4 + 3) * per + i] = u3;
+    }
+  }
+}
+
+// V[xi][c][t],  t = (n*TH + ty)*TW + tx,  d = x[n][c][2ty-1 .. 2ty+2][2tx-1 .. 2tx+2] (zero outside)
+__global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W,
+                                  long Tpad) {
+  const int TH = H / 2, TW = W / 2;
+  const long T = (long)N * TH * TW;
+  const long total = (long)C * T;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i % T;
+    const int c = (int)(i / T);
+    const int tx = (int)(t % TW);
+    const long r = t / TW;
+    const int ty = (int)(r % TH), n = (int)(r / TH);
+    const float* src = x + ((long)n * C + c) * H * W;
+    float d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int yy = 2 * ty - 1 + a;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int xx = 2 * tx - 1 + b;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float v = src[ok ? yy * W + xx : 0];
+        d[a][b] = ok ? v : 0.f;
+      }
+    }
+    // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
+    float bd[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      bd[0][b] = d[0][b] - d[2][b];
+      bd[1][b] = d[1][b] + d[2][b];
+      bd[2][b] = d[2][b] - d[1][b];
+      bd[3][b] = d[1][b] - d[3][b];
+    }
+    const long per = (long)C * Tpad;
+    float* dst = V + (long)c * Tpad + t;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      dst[(long)(a * 4 + 0) * per] = bd[a][0] - bd[a][2];
+      dst[(long)(a * 4 + 1) * per] = bd[a][1] + bd[a][2];
+      dst[(long)(a * 4 + 2) * per] = bd[a][2] - bd[a][1];
+      dst[(long)(a * 4 + 3) * per] = bd[a][1] - bd[a][3];
+    }
+  }
+}
+
+// y[n][m][2ty+i][2tx+j] = epilogue( (A^T M A)[i][j] ),  A^T = [1 1 1 0; 0 1 -1 -1]
+__global__ void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
+                                   const float* __restrict__ mask, float* __restrict__ y, int N, int Mch, int H,
+                                   int W, long Tpad, int Mpad, int relu) {
+  const int TH = H / 2, TW = W / 2;
+  const long T = (long)N * TH * TW;
+  const long total = (long)Mch * T;
+  const long per = (long)Mpad * Tpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i % T;
+    const int m = (int)(i / T);
+    const int tx = (int)(t % TW);
+    const long r = t / TW;
+    const int ty = (int)(r % TH), n = (int)(r / TH);
+    const float* src = Mx + (long)m * Tpad + t;
+    float mm[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) mm[a][b] = src[(long)(a * 4 + b) * per];
+    float am[2][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      am[0][b] = mm[0][b] + mm[1][b] + mm[2][b];
+      am[1][b] = mm[1][b] - mm[2][b] - mm[3][b];
+    }
+    float o[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      o[a][0] = am[a][0] + am[a][1] + am[a][2];
+      o[a][1] = am[a][1] - am[a][2] - am[a][3];
+    }
+    const float bv = bias ? bias[m] : 0.f;
+    const long ob = (((long)n * Mch + m) * H + 2 * ty) * W + 2 * tx;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float v0 = o[a][0] + bv, v1 = o[a][1] + bv;
+      if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      const long oo = ob + (long)a * W;
+      if (mask) {
+        const float2 mk = *reinterpret_cast<const float2*>(mask + oo);
+        v0 = mk.x > 0.f ? v0 : 0.f; v1 = mk.y > 0.f ? v1 : 0.f;
+      }
+      *reinterpret_cast<float2*>(y + oo) = make_float2(v0, v1);
+    }
+  }
+}
+
+struct WinoGemmParams {
+  const float* U;   // [16][MT][S][32][128]
+  const float* V;   // [16][C][Tpad]
+  float* Mx;        // [16][Mpad][Tpad]
+  int MT, S, C;
+  long Tpad;        // multiple of 128
+  int Mpad;         // MT * 128
+};
+
+// grid.x = 16 * TT * MT, XCD-aware: the MT workgroups that share one V tile get consecutive slots on one XCD
+__global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmParams p) {
+  constexpr int LDA = WLDA, LDB = WBN;
+  constexpr int TM = 2, TN = 2;
+  constexpr int KS = WK / 2;                 // 16 MFMA k-steps per stage
+  constexpr int NV = 4;                      // float4 units per thread per operand per stage
+  constexpr int SFLUSH = 4;                  // stages per MFMA accumulation chain (128 k)
+  __shared__ __attribute__((aligned(16))) float As[2][WK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WK * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const long TT = p.Tpad / WBN;
+  const int xcd = blockIdx.x & 7;
+  const long qq = blockIdx.x >> 3;
+  const int mt = (int)(qq % p.MT);
+  const long bt = (qq / p.MT) * 8 + xcd;     // (xi, t-tile) index
+  if (bt >= 16 * TT) return;
+  const int xi = (int)(bt / TT);
+  const long t0 = (bt % TT) * WBN;
+  const float* Ub = p.U + (((long)xi * p.MT + mt) * p.S) * (WK * WBM);
+  const float* Vb = p.V + (long)xi * p.C * p.Tpad + t0;
+
+  // staging geometry: unit u = tid + 256 v -> row k = u / 32, quad q = u % 32 (both operands are [32][128] images)
+  int lrow[NV], lq[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { const int u = tid + 256 * v; lrow[v] = u >> 5; lq[v] = u & 31; }
+  float4 ra[NV], rb[NV];
+  unsigned okb = 0;
+  auto load_a = [&](int v, int s) { ra[v] = *reinterpret_cast<const float4*>(Ub + (long)s * (WK * WBM) + lrow[v] * WBM + 4 * lq[v]); };
+  auto load_b = [&](int v, int s) {
+    const int c = s * WK + lrow[v];
+    const bool ok = c < p.C;
+    rb[v] = *reinterpret_cast<const float4*>(Vb + (ok ? (long)c * p.Tpad + 4 * lq[v] : 0));
+    okb = (okb & ~(1u << v)) | ((unsigned)ok << v);
+  };
+  auto store_a = [&](int v, int buf) { *reinterpret_cast<float4*>(&As[buf][lrow[v] * LDA + 4 * lq[v]]) = ra[v]; };
+  auto store_b = [&](int v, int buf) {
+    const bool ok = (okb >> v) & 1;
+    *reinterpret_cast<float4*>(&Bs[buf][lrow[v] * LDB + 4 * lq[v]]) = ok ? rb[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  f32x16 acc[TM][TN], tot[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+  const int ns = p.S;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { load_a(v, 0); load_b(v, 0); }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { store_a(v, 0); store_b(v, 0); }
+  __syncthreads();
+  for (int s0 = 0; s0 < ns; s0 += SFLUSH) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int s1 = min(ns, s0 + SFLUSH);
+    for (int s = s0; s < s1; ++s) {
+      const int cur = s & 1;
+      const int sn = min(s + 1, ns - 1);
+      const float* as = As[cur] + half * LDA + wm * 64 + l31;
+      const float* bs = Bs[cur] + half * LDB + wn * 64 + l31;
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const int cb = kk & 1, nb = cb ^ 1;
+        const int k1 = kk + 1;
+#pragma unroll
+        for (int m = 0; m < TM * TN; ++m) {
+          const int i = m / TN, j = m % TN;
+          acc[i][j] = mfma32(a[cb][i], b[cb][j], acc[i][j]);
+          if (m == 0 && k1 < KS) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) a[nb][ii] = as[2 * k1 * LDA + ii * 32];
+          }
+          if (m == 1 && k1 < KS) {
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) b[nb][jj] = bs[2 * k1 * LDB + jj * 32];
+          }
+          if (m == 3) {  // one staging piece per k-step: 8 loads, then 8 stores
+            if (kk < NV) load_a(kk, sn);
+            else if (kk < 2 * NV) load_b(kk - NV, sn);
+            else if (kk < 3 * NV) store_a(kk - 2 * NV, cur ^ 1);
+            else store_b(kk - 3 * NV, cur ^ 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
+  }
+  float* Mb = p.Mx + ((long)xi * p.Mpad + mt * WBM) * p.Tpad + t0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Mb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Tpad + wn * 64 + j * 32 + l31] = tot[i][j][r];
+}
+
+inline int nblk(long n, int cap) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+// workspace: U [16][MT*128][S*32] + V [16][C][Tpad] + M [16][MT*128][Tpad]  (floats)
+size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W) {
+  const long T = (long)N * (H / 2) * (W / 2);
+  const long Tpad = (T + WBN - 1) / WBN * WBN;
+  const long MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
+  return (size_t)16 * (MT * WBM * S * WK + (long)C * Tpad + MT * WBM * Tpad) + 64;
+}
+
+// forward (transposed = 0) or data gradient (transposed = 1), same contract as umpr_conv3x3_run
+int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
+                      int N, int Cin, int Cout, int H, int W, int relu, float* ws, size_t ws_floats, hipStream_t s) {
+  UMPR_REQUIRE((H % 2) == 0 && (W % 2) == 0, "winograd: odd map %dx%d", H, W);
+  const int M = transposed ? Cin : Cout;
+  const int C = transposed ? Cout : Cin;
+  UMPR_REQUIRE(ws_floats >= umpr_wino_ws_floats(N, C, M, H, W), "winograd: workspace too small");
+  const long T = (long)N * (H / 2) * (W / 2);
+  const long Tpad = (T + WBN - 1) / WBN * WBN;
+  const int MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
+  float* U = ws;
+  float* V = U + (size_t)16 * MT * WBM * S * WK;
+  float* Mx = V + (size_t)16 * C * Tpad;
+  wino_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
+  UMPR_LAUNCH_CHECK("wino_weights");
+  if (Tpad != T) {  // the padded tail of V must be finite (its products land in padded M columns that are never read)
+    if (hipMemsetAsync(V, 0, (size_t)16 * C * Tpad * sizeof(float), s) != hipSuccess) { umpr_set_error("winograd: memset"); return -2; }
+  }
+  wino_input_kernel<<<nblk((long)C * T, 16384), 256, 0, s>>>(x, V, N, C, H, W, Tpad);
+  UMPR_LAUNCH_CHECK("wino_input");
+  WinoGemmParams p{U, V, Mx, MT, S, C, Tpad, MT * WBM};
+  const long TT = Tpad / WBN;
+  const long groups = (16 * TT + 7) / 8 * 8;
+  wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+  UMPR_LAUNCH_CHECK("wino_gemm");
+  wino_output_kernel<<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
+  UMPR_LAUNCH_CHECK("wino_output");
+  return 0;
+}
