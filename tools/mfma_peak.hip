@@ -15,17 +15,21 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters,
   for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   float a0 = in[lane], a1 = in[64 + lane], b0 = in[128 + lane], b1 = in[192 + lane];
   unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  const float* sp = S + (lane & 31) + (lane >> 5) * 130;
+  const float* sp0 = S + (lane & 31) + (lane >> 5) * 130;
   for (int it = 0; it < iters; ++it) {
+    // the address depends on `it` (and on a value the compiler cannot see), so the reads stay inside the loop
+    const float* sp = sp0 + ((it & 1) ^ (iters & 1)) * 32 * 130;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-      if (LDSREAD) {
+      if (LDSREAD == 1) {
         na0 = sp[(2 * kk) * 130]; na1 = sp[(2 * kk) * 130 + 32]; nb0 = sp[(2 * kk) * 130 + 64]; nb1 = sp[(2 * kk) * 130 + 96];
         __builtin_amdgcn_sched_barrier(0);
       }
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+      if (LDSREAD == 2) { __builtin_amdgcn_sched_barrier(0); na0 = sp[(2 * kk) * 130]; na1 = sp[(2 * kk) * 130 + 32]; __builtin_amdgcn_sched_barrier(0); }
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+      if (LDSREAD == 2) { __builtin_amdgcn_sched_barrier(0); nb0 = sp[(2 * kk) * 130 + 64]; nb1 = sp[(2 * kk) * 130 + 96]; __builtin_amdgcn_sched_barrier(0); }
       acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
       if (LDSREAD) __builtin_amdgcn_sched_barrier(0);
@@ -46,12 +50,13 @@ int main(int argc, char** argv) {
   float* h = (float*)malloc(4096 * 4);
   for (int i = 0; i < 4096; ++i) h[i] = (float)rand() / RAND_MAX - 0.5f;
   hipMemcpy(in, h, 4096 * 4, hipMemcpyHostToDevice);
-  for (int lds = 0; lds < 2; ++lds)
+  for (int lds = 0; lds < 3; ++lds)
     for (int blocks : {256, 512, 1024}) {
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        if (lds) k<1><<<blocks, 256>>>(out, in, iters, clk); else k<0><<<blocks, 256>>>(out, in, iters, clk);
+        if (lds == 2) k<2><<<blocks, 256>>>(out, in, iters, clk);
+        else if (lds) k<1><<<blocks, 256>>>(out, in, iters, clk); else k<0><<<blocks, 256>>>(out, in, iters, clk);
         hipEventRecord(e1); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -63,15 +63,22 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-// V[xi][c][t],  t = (n*TH + ty)*TW + tx,  d = x[n][c][2ty-1 .. 2ty+2][2tx-1 .. 2tx+2] (zero outside)
-__global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W,
-                                  long Tpad) {
+// V[xi][c][t] (c < Cpad = S * 32),  t = (n*TH + ty)*TW + tx,  d = x[n][c][2ty-1 .. 2ty+2][2tx-1 .. 2tx+2] (zero outside)
+__global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int Cpad, int H,
+                                  int W, long Tpad, long Tw) {
   const int TH = H / 2, TW = W / 2;
   const long T = (long)N * TH * TW;
-  const long total = (long)C * T;
+  const long total = (long)Cpad * Tw;   // channels / tiles rounded up to the GEMM tile: the padding is written as zeros
+  const long per = (long)Cpad * Tpad;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long t = i % T;
-    const int c = (int)(i / T);
+    const long t = i % Tw;
+    const int c = (int)(i / Tw);
+    float* dst = V + (long)c * Tpad + t;
+    if (t >= T || c >= C) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) dst[(long)a * per] = 0.f;
+      continue;
+    }
     const int tx = (int)(t % TW);
     const long r = t / TW;
     const int ty = (int)(r % TH), n = (int)(r / TH);
@@ -97,8 +104,6 @@ __global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict
       bd[2][b] = d[2][b] - d[1][b];
       bd[3][b] = d[1][b] - d[3][b];
     }
-    const long per = (long)C * Tpad;
-    float* dst = V + (long)c * Tpad + t;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       dst[(long)(a * 4 + 0) * per] = bd[a][0] - bd[a][2];
@@ -157,12 +162,15 @@ __global__ void wino_output_kernel(const float* __restrict__ Mx, const float* __
   }
 }
 
+static long wino_tpad(long T) { return (T + WBN - 1) / WBN * WBN; }
+
 struct WinoGemmParams {
   const float* U;   // [16][MT][S][32][128]
-  const float* V;   // [16][C][Tpad]
+  const float* V;   // [16][S*32][Tpad]
   float* Mx;        // [16][Mpad][Tpad]
   int MT, S, C;
-  long Tpad;        // multiple of 128
+  long Tpad;        // >= TT * 128
+  long TT;          // 128-wide tile columns
   int Mpad;         // MT * 128
 };
 
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
-  const long TT = p.Tpad / WBN;
+  const long TT = p.TT;
   const int xcd = blockIdx.x & 7;
   const long qq = blockIdx.x >> 3;
   const int mt = (int)(qq % p.MT);
@@ -187,25 +195,39 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmParams p) {
   const int xi = (int)(bt / TT);
   const long t0 = (bt % TT) * WBN;
   const float* Ub = p.U + (((long)xi * p.MT + mt) * p.S) * (WK * WBM);
-  const float* Vb = p.V + (long)xi * p.C * p.Tpad + t0;
+  const float* Vb = p.V + (long)xi * (p.S * WK) * p.Tpad + t0;
 
-  // staging geometry: unit u = tid + 256 v -> row k = u / 32, quad q = u % 32 (both operands are [32][128] images)
-  int lrow[NV], lq[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) { const int u = tid + 256 * v; lrow[v] = u >> 5; lq[v] = u & 31; }
-  float4 ra[NV], rb[NV];
-  unsigned okb = 0;
-  auto load_a = [&](int v, int s) { ra[v] = *reinterpret_cast<const float4*>(Ub + (long)s * (WK * WBM) + lrow[v] * WBM + 4 * lq[v]); };
-  auto load_b = [&](int v, int s) {
-    const int c = s * WK + lrow[v];
-    const bool ok = c < p.C;
-    rb[v] = *reinterpret_cast<const float4*>(Vb + (ok ? (long)c * p.Tpad + 4 * lq[v] : 0));
-    okb = (okb & ~(1u << v)) | ((unsigned)ok << v);
-  };
-  auto store_a = [&](int v, int buf) { *reinterpret_cast<float4*>(&As[buf][lrow[v] * LDA + 4 * lq[v]]) = ra[v]; };
-  auto store_b = [&](int v, int buf) {
-    const bool ok = (okb >> v) & 1;
-    *reinterpret_cast<float4*>(&Bs[buf][lrow[v] * LDB + 4 * lq[v]]) = ok ? rb[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // staging: unit u = tid + 256 v covers row k = u / 32, quad q = u % 32 of a [32][128] operand image, i.e. float
+  // offset 4u in the U image and (k, 4q) in V.  Named registers (no arrays): hipcc spills indexed float4 arrays here.
+  const float* pa = Ub + 4 * tid;
+  const float* pb = Vb + (long)(tid >> 5) * p.Tpad + 4 * (tid & 31);
+  const long bstep = 8 * p.Tpad;
+  float* sa = &As[0][(tid >> 5) * LDA + 4 * (tid & 31)];
+  float* sb = &Bs[0][(tid >> 5) * LDB + 4 * (tid & 31)];
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  auto lda = [&](int v, int s) { return *reinterpret_cast<const float4*>(pa + (long)s * (WK * WBM) + 1024 * v); };
+  auto ldb = [&](int v, int s) { return *reinterpret_cast<const float4*>(pb + (long)s * 4 * bstep + v * bstep); };
+  auto sta = [&](int v, int buf, const float4& r) { *reinterpret_cast<float4*>(sa + buf * (WK * LDA) + 8 * v * LDA) = r; };
+  auto stb = [&](int v, int buf, const float4& r) { *reinterpret_cast<float4*>(sb + buf * (WK * LDB) + 8 * v * LDB) = r; };
+  auto piece = [&](int q, int sn, int nbuf) {   // q = 0..15: 8 loads for stage sn, then 8 stores into buffer nbuf
+    switch (q) {
+      case 0: ra0 = lda(0, sn); break;
+      case 1: ra1 = lda(1, sn); break;
+      case 2: ra2 = lda(2, sn); break;
+      case 3: ra3 = lda(3, sn); break;
+      case 4: rb0 = ldb(0, sn); break;
+      case 5: rb1 = ldb(1, sn); break;
+      case 6: rb2 = ldb(2, sn); break;
+      case 7: rb3 = ldb(3, sn); break;
+      case 8: sta(0, nbuf, ra0); break;
+      case 9: sta(1, nbuf, ra1); break;
+      case 10: sta(2, nbuf, ra2); break;
+      case 11: sta(3, nbuf, ra3); break;
+      case 12: stb(0, nbuf, rb0); break;
+      case 13: stb(1, nbuf, rb1); break;
+      case 14: stb(2, nbuf, rb2); break;
+      default: stb(3, nbuf, rb3); break;
+    }
   };
 
   f32x16 acc[TM][TN], tot[TM][TN];
@@ -218,9 +240,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmParams p) {
 
   const int ns = p.S;
 #pragma unroll
-  for (int v = 0; v < NV; ++v) { load_a(v, 0); load_b(v, 0); }
-#pragma unroll
-  for (int v = 0; v < NV; ++v) { store_a(v, 0); store_b(v, 0); }
+  for (int q = 0; q < 16; ++q) piece(q, 0, 0);
   __syncthreads();
   for (int s0 = 0; s0 < ns; s0 += SFLUSH) {
 #pragma unroll
@@ -256,12 +276,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmParams p) {
 #pragma unroll
             for (int jj = 0; jj < TN; ++jj) b[nb][jj] = bs[2 * k1 * LDB + jj * 32];
           }
-          if (m == 3) {  // one staging piece per k-step: 8 loads, then 8 stores
-            if (kk < NV) load_a(kk, sn);
-            else if (kk < 2 * NV) load_b(kk - NV, sn);
-            else if (kk < 3 * NV) store_a(kk - 2 * NV, cur ^ 1);
-            else store_b(kk - 3 * NV, cur ^ 1);
-          }
+          if (m == 3) piece(kk, sn, cur ^ 1);   // one staging piece per k-step
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -290,12 +305,12 @@ inline int nblk(long n, int cap) {
 
 }  // namespace
 
-// workspace: U [16][MT*128][S*32] + V [16][C][Tpad] + M [16][MT*128][Tpad]  (floats)
+// workspace: U [16][MT*128][S*32] + V [16][S*32][Tpad] + M [16][MT*128][Tpad]  (floats)
 size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W) {
   const long T = (long)N * (H / 2) * (W / 2);
-  const long Tpad = (T + WBN - 1) / WBN * WBN;
+  const long Tpad = wino_tpad(T);
   const long MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
-  return (size_t)16 * (MT * WBM * S * WK + (long)C * Tpad + MT * WBM * Tpad) + 64;
+  return (size_t)16 * (MT * WBM * S * WK + S * WK * Tpad + MT * WBM * Tpad) + 64;
 }
 
 // forward (transposed = 0) or data gradient (transposed = 1), same contract as umpr_conv3x3_run
@@ -306,20 +321,17 @@ int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const floa
   const int C = transposed ? Cout : Cin;
   UMPR_REQUIRE(ws_floats >= umpr_wino_ws_floats(N, C, M, H, W), "winograd: workspace too small");
   const long T = (long)N * (H / 2) * (W / 2);
-  const long Tpad = (T + WBN - 1) / WBN * WBN;
+  const long Tpad = wino_tpad(T);
   const int MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
   float* U = ws;
   float* V = U + (size_t)16 * MT * WBM * S * WK;
-  float* Mx = V + (size_t)16 * C * Tpad;
+  float* Mx = V + (size_t)16 * S * WK * Tpad;
   wino_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
   UMPR_LAUNCH_CHECK("wino_weights");
-  if (Tpad != T) {  // the padded tail of V must be finite (its products land in padded M columns that are never read)
-    if (hipMemsetAsync(V, 0, (size_t)16 * C * Tpad * sizeof(float), s) != hipSuccess) { umpr_set_error("winograd: memset"); return -2; }
-  }
-  wino_input_kernel<<<nblk((long)C * T, 16384), 256, 0, s>>>(x, V, N, C, H, W, Tpad);
+  const long TT = (T + WBN - 1) / WBN;
+  wino_input_kernel<<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
   UMPR_LAUNCH_CHECK("wino_input");
-  WinoGemmParams p{U, V, Mx, MT, S, C, Tpad, MT * WBM};
-  const long TT = Tpad / WBN;
+  WinoGemmParams p{U, V, Mx, MT, S, C, Tpad, TT, MT * WBM};
   const long groups = (16 * TT + 7) / 8 * 8;
   wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
   UMPR_LAUNCH_CHECK("wino_gemm");
