@@ -177,6 +177,16 @@ int umpr_head_bwd(const float* rr, const float* c_u, const float* c_i, const flo
                   float* d_rr, float* d_cu, float* d_ci, float* d_pp, float* d_pn, float* d_vgg, float* d_pos_v,
                   float* d_neg_v, float* d_lin_w, float* d_lin_b, float* d_fus_w, float* d_fus_b, void* stream);
 
+/* ---- R-Net pre-training head (pretrain/pretrain_rnet.py:147-169): result = sigmoid(Linear(K -> 1)(att)),
+ * loss = BCELoss(mean)(result, target) with torch's log clamp at -100.  att rows at att + b*ld (K = 256: [atte_u;atte_i]
+ * as umpr_coattention_fwd leaves them).  ws: B floats.  Backward follows ATen's binary_cross_entropy_backward
+ * (denominator max(p(1-p), 1e-12)); d_result may be NULL, d_loss is a device scalar. */
+int umpr_bce_head_fwd(const float* att, long ld, const float* w, const float* b, const float* target, int B, int K,
+                      float* result, float* loss, float* ws, size_t ws_bytes, void* stream);
+int umpr_bce_head_bwd(const float* att, long ld, const float* w, const float* result, const float* target,
+                      const float* d_result /*or NULL*/, const float* d_loss, int B, int K, float* d_att, long ld_d,
+                      float* dw, float* db, float* ws, size_t ws_bytes, void* stream);
+
 /* ---- K13: Adam step with coupled L2, as torch.optim.Adam drives it in main.py:22-26,37 ----------------------
  * One flat parameter segment: p,g,m,v [n]; step >= 1; grad_scale multiplies g first (1/world for data parallel). */
 int umpr_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,

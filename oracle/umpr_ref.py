@@ -283,3 +283,18 @@ def evaluate_mse(P, batches, **kw):
             tot += F.mse_loss(pred, b[-1], reduction="sum").item()
             cnt += len(pred)
     return tot / cnt
+
+
+def pretrain_rnet_forward(P: Dict[str, Tensor], u, u_length, i, i_length, target, aten=False):
+    """PretrainRNet.forward, pretrain/pretrain_rnet.py:155-169: one sentence per side (S = 1), R-Net co-attention,
+    ``sigmoid(Linear(4u -> 1)([atte_u; atte_i]))`` and ``nn.BCELoss`` (mean; ATen clamps the logs at -100)."""
+    emb = P["embedding.weight"]
+    B, L = u.shape
+    ue = F.embedding(u.view(B, 1, L), emb)
+    ie = F.embedding(i.view(B, 1, L), emb)
+    _, _, _, _, att_u, att_i = r_net(ue, ie, u_length.view(B, 1), i_length.view(B, 1), P, "r_net.", aten)
+    att = torch.cat([att_u, att_i], dim=-1)
+    result = torch.sigmoid(att @ P["linear.0.weight"].t() + P["linear.0.bias"]).squeeze(-1)
+    t = target.float()
+    terms = -(t * torch.clamp(torch.log(result), min=-100.0) + (1 - t) * torch.clamp(torch.log1p(-result), min=-100.0))
+    return result, terms.mean()

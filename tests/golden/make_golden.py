@@ -368,6 +368,49 @@ def gen_dataset():
     print("wrote dataset_golden.json", os.path.getsize(os.path.join(HERE, "dataset_golden.json")) // 1024, "KB")
 
 
+def gen_pretrain_rnet():
+    """PretrainRNet (pretrain/pretrain_rnet.py:144-169) forward / grads / 3 Adam steps as pretrain_rnet.py:177-198
+    drives them.  The module imports gensim and sklearn at the top; gensim gets an empty module object (never called)."""
+    sys.modules.setdefault("gensim", types.ModuleType("gensim"))
+    from pretrain.pretrain_rnet import PretrainRNet
+    from umpr_amd.synthetic import make_pretrain_batch, make_pretrain_state
+
+    class W2V:
+        pass
+
+    for tag, (B, L, ragged, pseed, bseed) in {"ragged": (6, 9, True, 41, 42), "full": (16, 20, False, 43, 44)}.items():
+        P = make_pretrain_state(pseed, 50, 300)
+        w2v = W2V()
+        w2v.embedding = P["embedding.weight"].numpy()
+        w2v.word_dim = 50
+        m = PretrainRNet(w2v, 64)
+        m.load_state_dict(P)
+        batch = make_pretrain_batch(bseed, B, L, 300, ragged)
+        result, loss = m(*batch)
+        loss.mean().backward()
+        out = {"meta": np.array([B, L, int(ragged), pseed, bseed]), "result": result.detach(), "loss": loss.detach()}
+        for n, g in grads_of(m).items():
+            out["grad/" + n] = g
+        # 3 optimiser steps, pretrain_rnet.py:177-198 (lr 0.01, l2 1e-3 on names without 'bias')
+        m.load_state_dict(P)
+        opt = torch.optim.Adam([
+            {'params': (p for name, p in m.named_parameters() if 'bias' not in name)},
+            {'params': (p for name, p in m.named_parameters() if 'bias' in name), 'weight_decay': 0.}
+        ], 0.01, weight_decay=1e-3)
+        losses = []
+        for step in range(3):
+            _, l = m(*batch)
+            l = l.mean()
+            opt.zero_grad()
+            l.backward()
+            opt.step()
+            losses.append(float(l))
+        out["traj_loss"] = np.array(losses)
+        for n, p_ in m.named_parameters():
+            out["traj_param/" + n] = p_.detach()
+        save("pretrain_rnet_" + tag, out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -375,6 +418,9 @@ def main():
     from src import model as refmodel  # the reference's own code
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
         gen_dataset()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "pretrain":
+        gen_pretrain_rnet()
         return
     gen_dataset()
     gen_improved_rnn(refmodel)
@@ -389,6 +435,7 @@ def main():
     gen_umpr(refmodel, "umpr_full_V4_B2", B=2, n_views=4, review_net_only=False, m_scale=0.05, pseed=55, bseed=56)
     gen_umpr(refmodel, "umpr_full_V1_B2_drop", B=2, n_views=1, review_net_only=False, m_scale=0.05, pseed=57, bseed=58,
              drop_masks=True)
+    gen_pretrain_rnet()
 
 
 if __name__ == "__main__":

@@ -564,3 +564,91 @@ def test_full_size_properties(L, dev):
            ws.numel() * 4, st())                                             # natural grouping, no permutation
     # out_sorted[order[n]] is sequence n (dst_row = sorted_indices); compare with the unpermuted run bit for bit
     assert torch.equal(out_sorted[order.long()], out_ident), "GRU output depends on tile grouping"
+
+
+# ------------------------------------------------------------------------------------------------ R-Net pre-training
+class _W2V:
+    def __init__(self, P):
+        self.embedding = P["embedding.weight"].numpy()
+        self.word_dim = self.embedding.shape[1]
+
+
+def test_bce_head_kernel(L, dev):
+    g = torch.Generator().manual_seed(17)
+    B, K = 37, 256
+    att = torch.randn(B, K, generator=g).requires_grad_(True)
+    w = (torch.randn(1, K, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(1, generator=g).requires_grad_(True)
+    att.data[0] *= 40  # saturated rows: p -> 0 / 1, exercises the -100 log clamp and the 1e-12 denominator
+    att.data[1] *= -40
+    tgt = torch.randint(0, 2, (B,), generator=g).float()
+    res_ref = torch.sigmoid(att @ w.t() + b).squeeze(-1)
+    loss_ref = F.binary_cross_entropy(res_ref, tgt)
+    gl = torch.tensor(0.7)
+    loss_ref.backward(gl)
+    ad, wd, bd, td = att.detach().to(dev), w.detach().to(dev), b.detach().to(dev), tgt.to(dev)
+    res, loss = torch.empty(B, device=dev), torch.empty((), device=dev)
+    ws = torch.empty(B, device=dev)
+    L.call("umpr_bce_head_fwd", ad, K, wd, bd, td, B, K, res, loss, ws, B * 4, st())
+    check("bce result", res, res_ref, atol=1e-6)
+    check("bce loss", loss, loss_ref, atol=1e-5, rtol=1e-6)
+    d_att, dw, db = torch.empty(B, K, device=dev), torch.empty(1, K, device=dev), torch.empty(1, device=dev)
+    L.call("umpr_bce_head_bwd", ad, K, wd, res, td, None, gl.to(dev), B, K, d_att, K, dw, db, ws, B * 4, st())
+    check("bce d_att", d_att, att.grad, atol=1e-7, rtol=1e-5)
+    check("bce dw", dw, w.grad, atol=1e-5, rtol=1e-5)
+    check("bce db", db, b.grad, atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["ragged", "full"])
+def test_pretrain_rnet_golden(dev, tag):
+    """PretrainRNet (pretrain/pretrain_rnet.py:144-169) through the C ABI against the reference's outputs, gradients
+    and 3-step Adam trajectory (pretrain_rnet.py:177-198)."""
+    from umpr_amd.optim import FusedAdam
+    from umpr_amd.pretrain import PretrainRNet
+    from umpr_amd.synthetic import make_pretrain_batch, make_pretrain_state
+    g = load_golden("pretrain_rnet_" + tag)
+    B, Lmax, ragged, pseed, bseed = [int(v) for v in g["meta"]]
+    P = make_pretrain_state(pseed, 50, 300)
+    batch = make_pretrain_batch(bseed, B, Lmax, 300, bool(ragged))
+    m = PretrainRNet(_W2V(P), 64)
+    m.load_state_dict(P)
+    m = m.to(dev)
+    result, loss = m(*batch)
+    check("pretrain result", result, g["result"], atol=1e-5)
+    check("pretrain loss", loss, g["loss"], atol=1e-5)
+    loss.backward()
+    for k, p in m.named_parameters():
+        if "grad/" + k in g:
+            check("pretrain grad " + k, p.grad, g["grad/" + k], atol=1e-6, rel_to_max=1e-3)
+    m.load_state_dict(P)
+    opt = FusedAdam(m, 0.01, 1e-3)
+    for step in range(3):
+        _, l = m(*batch)
+        opt.zero_grad()
+        l.backward()
+        opt.step()
+        log(f"pretrain step {step}: loss {l.item():.6f} ref {g['traj_loss'][step]:.6f}")
+        assert abs(l.item() - g["traj_loss"][step]) < 1e-4
+    for k, p in m.named_parameters():
+        if "traj_param/" + k in g and p.requires_grad:
+            check("pretrained " + k, p, g["traj_param/" + k], atol=2e-4, rtol=1e-3)
+
+
+def test_pretrain_rnet_loop_saves_rnet(dev, tmp_path):
+    """pretrain_r_net (pretrain_rnet.py:172-205): the loss falls on a learnable toy task and save_r_net writes a
+    state_dict that loads into an RNet, i.e. into UMPR's review_net.r_net (the reference only saves the module,
+    pretrain_rnet.py:170,205; its main.py has no loader)."""
+    from umpr_amd.pretrain import pretrain_r_net
+    from umpr_amd.synthetic import make_pretrain_batch, make_pretrain_state
+    P = make_pretrain_state(45, 50, 300)
+    batches = [make_pretrain_batch(46 + k, 64, 12, 300, True) for k in range(2)]
+    lines = []
+    path = str(tmp_path / "rnet.pt")
+    model = pretrain_r_net(_W2V(P), batches, path, learning_rate=0.01, train_epochs=4, log=lines.append)
+    first, last = float(lines[0].split()[-1]), float(lines[-1].split()[-1])
+    log(f"pretrain loop loss {first:.4f} -> {last:.4f}")
+    assert last < first
+    sd = torch.load(path, weights_only=True)
+    assert set(sd) == set(model.r_net.state_dict())
+    from umpr_amd.model import RNet
+    RNet(50, 64).load_state_dict(sd)

@@ -108,3 +108,23 @@ def test_adam_trajectory():
     for k, p in P.items():
         if "param/" + k in g:
             np.testing.assert_allclose(p.detach().numpy(), g["param/" + k], atol=2e-6, rtol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["ragged", "full"])
+@pytest.mark.parametrize("aten", [False, True])
+def test_pretrain_rnet(tag, aten):
+    """Oracle restatement of PretrainRNet.forward (pretrain/pretrain_rnet.py:155-169) against the reference's own
+    outputs and gradients (fixtures pretrain_rnet_*: generated by tests/golden/make_golden.py from the reference)."""
+    from umpr_amd.synthetic import make_pretrain_batch, make_pretrain_state
+    g = load_golden("pretrain_rnet_" + tag)
+    B, L, ragged, pseed, bseed = [int(v) for v in g["meta"]]
+    P = {k: v.requires_grad_(k != "embedding.weight") for k, v in make_pretrain_state(pseed, 50, 300).items()}
+    batch = make_pretrain_batch(bseed, B, L, 300, bool(ragged))
+    result, loss = R.pretrain_rnet_forward(P, *batch, aten=aten)
+    assert torch.allclose(result, t(g["result"]), atol=2e-6)
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    loss.backward()
+    for k, v in P.items():
+        if "grad/" + k in g:
+            ref = t(g["grad/" + k])
+            assert torch.allclose(v.grad, ref, atol=1e-6 + 1e-5 * float(ref.abs().max())), k

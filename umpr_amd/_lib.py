@@ -63,6 +63,8 @@ SIGNATURES = {
     "umpr_maxpool2_bwd_relu": ("pppliip", "i"),
     "umpr_head_fwd": ("pppppppppppppfiiipppppppp", "i"),
     "umpr_head_bwd": ("pppppppppppfiiippppppppppppppppppppp", "i"),
+    "umpr_bce_head_fwd": ("plpppiipppzp", "i"),
+    "umpr_bce_head_bwd": ("plpppppiiplpppzp", "i"),
     "umpr_adam_step": ("ppppldddddldp", "i"),
     "umpr_debug_poison_lds": ("pp", "i"),
     "umpr_profile_enable": ("i", "i"),

@@ -551,6 +551,17 @@ int umpr_profile_read(int family, double* total_ms, double* total_work, long* la
 }
 
 // ------------------------------------------------------------------------------------------------ Adam
+int umpr_bce_head_fwd(const float* att, long ld, const float* w, const float* b, const float* target, int B, int K,
+                      float* result, float* loss, float* ws, size_t ws_bytes, void* stream) {
+  return umpr_bce_head_fwd_impl(att, ld, w, b, target, B, K, result, loss, ws, ws_bytes, S(stream));
+}
+int umpr_bce_head_bwd(const float* att, long ld, const float* w, const float* result, const float* target,
+                      const float* d_result, const float* d_loss, int B, int K, float* d_att, long ld_d, float* dw,
+                      float* db, float* ws, size_t ws_bytes, void* stream) {
+  return umpr_bce_head_bwd_impl(att, ld, w, result, target, d_result, d_loss, B, K, d_att, ld_d, dw, db, ws, ws_bytes,
+                                S(stream));
+}
+
 int umpr_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, long step, double grad_scale, void* stream) {
   UMPR_REQUIRE(step >= 1 && n >= 0, "adam: bad step/n");

@@ -794,3 +794,94 @@ int umpr_head_launch(const UmprHead& p, int backward, hipStream_t s) {
   }
   return 0;
 }
+
+// ---- R-Net pre-training head (pretrain/pretrain_rnet.py:147-169): sigmoid(Linear(256 -> 1)) + BCELoss(mean) ------
+namespace {
+
+// one wave per sample: z = att . w + b, p = sigmoid(z), term = -(t log p + (1 - t) log(1 - p)) with torch's -100 clamp
+__global__ void bce_head_fwd_kernel(const float* __restrict__ att, long ld, const float* __restrict__ w,
+                                    const float* __restrict__ b, const float* __restrict__ target, int B, int K,
+                                    float* __restrict__ result, float* __restrict__ terms) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += att[(long)row * ld + k] * w[k];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    const float z = acc + b[0];
+    const float p = 1.f / (1.f + expf(-z));
+    const float t = target[row];
+    result[row] = p;
+    terms[row] = -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(log1pf(-p), -100.f));
+  }
+}
+
+// single workgroup, fixed summation order: loss = mean(terms)
+__global__ void bce_mean_kernel(const float* __restrict__ terms, int B, float* __restrict__ loss) {
+  __shared__ float part[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) a += terms[i];
+  part[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
+}
+
+// dz[b] = d_loss/B * (p - t)/max(p(1-p), 1e-12) * p(1-p)  (+ d_result[b] * p(1-p));  d_att[b][k] = dz[b] w[k]
+__global__ void bce_head_bwd_rows_kernel(const float* __restrict__ w, const float* __restrict__ result,
+                                         const float* __restrict__ target, const float* __restrict__ d_result,
+                                         const float* __restrict__ d_loss, int B, int K, float* __restrict__ dz,
+                                         float* __restrict__ d_att, long ld_d) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  const float p = result[row], t = target[row];
+  const float pq = p * (1.f - p);
+  float g = d_loss[0] / (float)B * (p - t) / fmaxf(pq, 1e-12f);
+  if (d_result) g += d_result[row];
+  const float z = g * pq;
+  if (lane == 0) dz[row] = z;
+  for (int k = lane; k < K; k += 64) d_att[(long)row * ld_d + k] = z * w[k];
+}
+
+// dw[k] = sum_b dz[b] att[b][k] (thread per k, b ascending), db = sum_b dz[b] (thread K)
+__global__ void bce_head_bwd_w_kernel(const float* __restrict__ att, long ld, const float* __restrict__ dz, int B,
+                                      int K, float* __restrict__ dw, float* __restrict__ db) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > K) return;
+  float a = 0.f;
+  if (k < K) {
+    for (int b = 0; b < B; ++b) a += dz[b] * att[(long)b * ld + k];
+    dw[k] = a;
+  } else {
+    for (int b = 0; b < B; ++b) a += dz[b];
+    db[0] = a;
+  }
+}
+
+}  // namespace
+
+int umpr_bce_head_fwd_impl(const float* att, long ld, const float* w, const float* b, const float* target, int B, int K,
+                           float* result, float* loss, float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(B > 0 && K > 0 && ld >= K, "bce_head_fwd: bad shape B=%d K=%d ld=%ld", B, K, ld);
+  UMPR_REQUIRE(ws_bytes >= (size_t)B * sizeof(float), "bce_head_fwd: workspace too small");
+  bce_head_fwd_kernel<<<(B + 3) / 4, 256, 0, s>>>(att, ld, w, b, target, B, K, result, ws);
+  UMPR_LAUNCH_CHECK("bce_head_fwd");
+  bce_mean_kernel<<<1, 256, 0, s>>>(ws, B, loss);
+  UMPR_LAUNCH_CHECK("bce_mean");
+  return 0;
+}
+
+int umpr_bce_head_bwd_impl(const float* att, long ld, const float* w, const float* result, const float* target,
+                           const float* d_result, const float* d_loss, int B, int K, float* d_att, long ld_d, float* dw,
+                           float* db, float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(B > 0 && K > 0 && ld >= K && ld_d >= K, "bce_head_bwd: bad shape");
+  UMPR_REQUIRE(ws_bytes >= (size_t)B * sizeof(float), "bce_head_bwd: workspace too small");
+  bce_head_bwd_rows_kernel<<<(B + 3) / 4, 256, 0, s>>>(w, result, target, d_result, d_loss, B, K, ws, d_att, ld_d);
+  UMPR_LAUNCH_CHECK("bce_head_bwd_rows");
+  bce_head_bwd_w_kernel<<<(K + 1 + 63) / 64, 64, 0, s>>>(att, ld, ws, B, K, dw, db);
+  UMPR_LAUNCH_CHECK("bce_head_bwd_w");
+  return 0;
+}

@@ -90,6 +90,11 @@ int umpr_colsum(const float* src, long rows, int cols, long ld, float* dst, int 
                 hipStream_t s);
 int umpr_dropout_fwd_impl(const float* x, float* y, uint8_t* mask, long n, float p, uint64_t seed, int gen, hipStream_t s);
 int umpr_dropout_bwd_impl(const float* gy, const uint8_t* mask, const float* a, float* gx, long n, float p, hipStream_t s);
+int umpr_bce_head_fwd_impl(const float* att, long ld, const float* w, const float* b, const float* target, int B, int K,
+                           float* result, float* loss, float* ws, size_t ws_bytes, hipStream_t s);
+int umpr_bce_head_bwd_impl(const float* att, long ld, const float* w, const float* result, const float* target,
+                           const float* d_result, const float* d_loss, int B, int K, float* d_att, long ld_d, float* dw,
+                           float* db, float* ws, size_t ws_bytes, hipStream_t s);
 int umpr_adam_impl(float* p, const float* g, float* m, float* v, long n, float gscale, float wd, float b1, float b2,
                    float eps, float step_size, float inv_bc2_sqrt, hipStream_t s);
 int umpr_snet_fwd_impl(const float* X, const float* Ms, const float* Ws, const float* word_soft, int wl, int B, int S,

@@ -152,3 +152,40 @@ def make_batch(seed: int, B: int, vocab: int = 1000, n_views: int = 1, photo_cou
         photos[missing] = 0  # unreadable photo -> zeros (dataset.py:142-143)
     labels = torch.randint(1, 6, (B,), generator=g).float()
     return u_ids, i_ids, ui_ids, u_len, i_len, ui_len, photos, labels
+
+
+def make_pretrain_state(seed: int, emb_dim: int = 50, vocab: int = 1000, gru_size: int = 64,
+                        m_scale: float = 0.05, emb_std: float = 0.4) -> Dict[str, torch.Tensor]:
+    """state_dict of the reference's PretrainRNet (pretrain/pretrain_rnet.py:144-153) from a seed."""
+    g = torch.Generator().manual_seed(seed)
+    H, H2 = gru_size, 2 * gru_size
+    P: Dict[str, torch.Tensor] = {}
+    emb = torch.randn(vocab, emb_dim, generator=g) * emb_std
+    emb[:3] = 0
+    P["embedding.weight"] = emb
+    P["r_net.M"] = torch.randn(H2, H2, generator=g) * m_scale
+    k = 1.0 / math.sqrt(H)
+    for suf in ("", "_reverse"):
+        P[f"r_net.gru.module.weight_ih_l0{suf}"] = _uniform(g, (3 * H, emb_dim), k)
+        P[f"r_net.gru.module.weight_hh_l0{suf}"] = _uniform(g, (3 * H, H), k)
+        P[f"r_net.gru.module.bias_ih_l0{suf}"] = _uniform(g, (3 * H,), k)
+        P[f"r_net.gru.module.bias_hh_l0{suf}"] = _uniform(g, (3 * H,), k)
+    k = 1.0 / math.sqrt(2 * H2)
+    P["linear.0.weight"] = _uniform(g, (1, 2 * H2), k)
+    P["linear.0.bias"] = _uniform(g, (1,), k)
+    return P
+
+
+def make_pretrain_batch(seed: int, B: int, L: int = 20, vocab: int = 1000, ragged: bool = True):
+    """(u, u_length, i, i_length, target) as PretrainRNetDataset yields them (pretrain_rnet.py:129-135): padded id
+    rows [B, L] int64, lengths [B] int64, labels [B] float in {0, 1}.  The reference's dataset passes len(padded row)
+    = L as the length; ``ragged`` also exercises shorter lengths (the model accepts any 1 <= length <= L)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(2):
+        ids = torch.randint(3, vocab, (B, L), generator=g)
+        ln = torch.randint(1, L + 1, (B,), generator=g) if ragged else torch.full((B,), L, dtype=torch.int64)
+        ids = ids * (torch.arange(L)[None, :] < ln[:, None])
+        out += [ids, ln]
+    out.append(torch.randint(0, 2, (B,), generator=g).float())
+    return tuple(out)
