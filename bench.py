@@ -31,6 +31,20 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 
 GFLOP_PER_SAMPLE_TRAIN = 93.73  # SURVEY.md 8(d), cfg2 fully padded
 
 
+def pmc_traffic(launches_per_step):
+    """HBM-side bytes per launch of the conv forward+dgrad family from the committed rocprofv3 --pmc passes of this
+    build (profiles/README.md; FETCH_SIZE doubled per the guide's gfx950 correction).  bench.py cannot run the
+    counter passes itself, so the figure is the stored measurement, or None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        f = d["families"]["igemm_family"]
+        per_step = (2.0 * f["FETCH_SIZE"] + f["WRITE_SIZE"]) * 1024.0 / d["steps"]
+        return per_step / max(launches_per_step, 1), "bytes/launch from profiles/r01_e_pmc_traffic.json (batch 64 run)"
+    except Exception:
+        return None, "no stored PMC pass"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +172,7 @@ def main():
         dt = float(t.item())
 
     fam = {}
-    for name, idx in (("conv3x3_igemm", 0), ("conv3x3_wgrad", 1), ("gemm_f32", 2)):
+    for name, idx in (("conv3x3_igemm", 0), ("conv3x3_wgrad", 1), ("gemm_f32", 2), ("wino_gemm", 4)):
         ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
         L.fn["umpr_profile_read"](idx, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
         fam[name] = (ms.value, work.value, n.value)
@@ -167,6 +181,9 @@ def main():
         value = world * args.batch * args.steps / dt
         ms, work, n = fam["conv3x3_igemm"]
         achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # Winograd layers execute 1/2.25 of the direct-convolution FLOPs `achieved` counts for them
+        executed = (work - 1.25 * fam["wino_gemm"][1]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic(n / max(args.steps, 1))
         out = {
             "metric": "training samples/sec", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -178,8 +195,10 @@ def main():
                             + ", fp32, fwd+bwd+Adam(+RCCL all-reduce), random-init weights",
                 "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "conv3x3_igemm_kernel (VGG16 conv forward + dgrad)", "launches": n,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_note": traffic_note, "executed_tflops": executed,
+                         "kernel": "conv3x3 forward + dgrad family (direct implicit GEMM on 224/112 maps, Winograd "
+                                   "F(2x2,3x3) transforms + batched GEMM on 56/28/14 maps)", "launches": n,
                          "avg_launch_ms": ms / max(n, 1), "algorithmic_gflop_per_launch": work / max(n, 1) / 1e9},
             "kernels": {k: {"ms_per_step": v[0] / args.steps, "tflops": (v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0),
                             "launches_per_step": v[2] / args.steps} for k, v in fam.items()},

@@ -1,0 +1,33 @@
+# HBM-side traffic of the conv kernels (rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes as the guide
+# prescribes), summed per kernel family over one bench run of 2 steps.  Writes gpurun_out/pmc_traffic.json.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pt_$c
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pt_$c -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/pt_$c.out 2> /tmp/pt_$c.err || { echo "pass $c failed"; tail -5 /tmp/pt_$c.err; exit 1; }
+done
+python3 - <<'PY'
+import csv, glob, json, os, collections
+R = os.environ['GRAFT_REPO_ROOT']
+fam = lambda n: ('igemm_family' if any(k in n for k in ('conv3x3_igemm', 'wino_', 'pack_weights', 'conv3x3_fwd', 'conv3x3_dgrad'))
+                 else 'wgrad_family' if ('wgrad' in n) else None)
+out = collections.defaultdict(lambda: collections.defaultdict(float))
+per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.defaultdict(int)
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for f in glob.glob(f'/tmp/pt_{c}/*counter_collection.csv'):
+        for r in csv.DictReader(open(f)):
+            n = r['Kernel_Name']
+            short = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+            if r['Counter_Name'] != c:
+                continue
+            per_kernel[short][c] += float(r['Counter_Value'])
+            if c == 'FETCH_SIZE':
+                calls[short] += 1
+            if fam(n):
+                out[fam(n)][c] += float(r['Counter_Value'])
+res = {'steps': 2, 'unit': 'KB (rocprofv3 FETCH_SIZE / WRITE_SIZE raw sums over 2 steps)', 'families': out,
+       'kernels': {k: dict(v, dispatches=calls[k]) for k, v in per_kernel.items() if any(s in k for s in ('conv', 'wino', 'pack'))}}
+json.dump(res, open(R + '/gpurun_out/pmc_traffic.json', 'w'), indent=1)
+print(json.dumps(res['families'], indent=1))
+PY

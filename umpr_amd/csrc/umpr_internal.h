@@ -123,7 +123,9 @@ int umpr_gate_bwd_impl(const float* sa, const float* w, const float* view_p, con
 
 // ---- in-library kernel timing (bench.py roofline): HIP events recorded on the launch stream around the kernels of
 // one family while profiling is enabled.  Zero cost when disabled.
-enum UmprKernelFamily { UMPR_K_CONV_IGEMM = 0, UMPR_K_CONV_WGRAD = 1, UMPR_K_GEMM = 2, UMPR_K_GRU = 3, UMPR_K_COUNT = 4 };
+enum UmprKernelFamily { UMPR_K_CONV_IGEMM = 0, UMPR_K_CONV_WGRAD = 1, UMPR_K_GEMM = 2, UMPR_K_GRU = 3,
+                        UMPR_K_WINO_GEMM = 4 /* nested inside CONV_IGEMM: executed MFMA FLOPs of the Winograd GEMM */,
+                        UMPR_K_COUNT = 5 };
 struct UmprProfScope {
   UmprProfScope(int family, double work, hipStream_t s);
   ~UmprProfScope();

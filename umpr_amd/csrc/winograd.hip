@@ -333,7 +333,10 @@ int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const floa
   UMPR_LAUNCH_CHECK("wino_input");
   WinoGemmParams p{U, V, Mx, MT, S, C, Tpad, TT, MT * WBM};
   const long groups = (16 * TT + 7) / 8 * 8;
-  wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+  {
+    UmprProfScope prof(UMPR_K_WINO_GEMM, 2.0 * 16 * (double)M * C * T, s);
+    wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+  }
   UMPR_LAUNCH_CHECK("wino_gemm");
   wino_output_kernel<<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
   UMPR_LAUNCH_CHECK("wino_output");
