@@ -1,0 +1,175 @@
+"""End-to-end GPU tests of the host drivers around the kernels: evaluate_mse ("test MSE", src/evaluate.py:6-14), the
+CSV / GloVe / photos.json pipeline feeding the model (main.py:64-99), exact checkpoint resume, and the main.py CLI.
+The checker is the oracle (oracle/umpr_ref.py) on the same collated batches."""
+import os
+import shutil
+import sys
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+CORPUS = os.path.join(GOLDEN, "tiny_corpus")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _cfg(**kw):
+    from umpr_amd.config import Config
+    cfg = Config(argv=[])
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def test_evaluate_mse_vs_oracle(dev):
+    """Test MSE of the full model over two batches of different sizes = the oracle's, to 1e-4 (north_star)."""
+    from oracle import umpr_ref as R
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import evaluate_mse
+    P = make_param_state(81, 50, 600, 1, False, m_scale=0.05)
+    batches = [make_batch(82, 2, 600, 1), make_batch(83, 1, 600, 1)]
+    model = UMPR(_cfg(views=["unknown"]), P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    model = model.to(dev)
+    got = evaluate_mse(model, batches)
+    se, n = 0.0, 0
+    with torch.no_grad():
+        for b in batches:
+            pred, _ = R.umpr_forward(P, b, review_net_only=False, aten=True)
+            se += float(((pred - b[-1]) ** 2).sum())
+            n += len(pred)
+    assert abs(got - se / n) < 1e-4, (got, se / n)
+    assert not model.training  # evaluate_mse leaves the model in eval mode, like the reference
+
+
+@pytest.mark.parametrize("review_net_only", [True, False])
+def test_csv_pipeline_feeds_model(dev, review_net_only):
+    """train.csv + glove.txt + photos.json -> Dataset -> DataLoader(batch_loader) -> UMPR on the GPU.  Eval-mode
+    (prediction, loss) of every batch equal the oracle's on the same collated tensors; photo files that cannot be read
+    become zero images (src/dataset.py:142-143) on both sides."""
+    from torch.utils.data import DataLoader
+    from oracle import umpr_ref as R
+    from umpr_amd.data import Dataset, Word2vec, batch_loader
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_param_state
+    cfg = _cfg(max_sent_count=6, min_sent_count=2, max_ui_sent_count=3, max_sent_length=10, photo_count=1,
+               views=["food"], review_net_only=review_net_only, batch_size=3)
+    w2v = Word2vec(os.path.join(CORPUS, "glove.txt"))
+    ds = Dataset(os.path.join(CORPUS, "train.csv"), os.path.join(CORPUS, "photos.json"), os.path.join(CORPUS, "photos"),
+                 w2v, cfg)
+    assert len(ds) >= 4
+    loader = DataLoader(ds, batch_size=cfg.batch_size, collate_fn=lambda x: batch_loader(x, review_net_only))
+    E = w2v.embedding.shape[1]
+    P = make_param_state(91, E, len(w2v), 1, review_net_only, m_scale=0.05)
+    P["embedding.weight"] = torch.tensor(w2v.embedding, dtype=torch.float32)
+    model = UMPR(cfg, w2v.embedding)
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    n = 0
+    for batch in loader:
+        if n >= 2:
+            break
+        with torch.no_grad():
+            pred, loss = model(*batch)
+            rp, rl = R.umpr_forward(P, batch, review_net_only=review_net_only, aten=True)
+        assert torch.allclose(pred.cpu(), rp, atol=1e-4), (pred.cpu(), rp)
+        assert abs(float(loss) - float(rl)) < 1e-4
+        if not review_net_only:
+            assert batch[6].shape[1:] == (1, 1, 3, 224, 224) and float(batch[6].abs().max()) == 0.0
+        n += 1
+    assert n == 2
+
+
+def test_checkpoint_resume_is_exact(dev, tmp_path):
+    """4 training steps == 2 steps + save + load into a fresh model/optimiser + 2 steps, bit for bit (parameters and
+    Adam moments travel; the kernels are deterministic)."""
+    from umpr_amd.checkpoint import load_checkpoint, save_checkpoint
+    from umpr_amd.model import UMPR
+    from umpr_amd.optim import FusedAdam
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import train_step
+    P = make_param_state(101, 50, 500, 1, True, m_scale=0.05)
+    cfg = _cfg(review_net_only=True)
+    batches = [make_batch(110 + i, 4, 500, review_net_only=True) for i in range(4)]
+
+    def fresh():
+        m = UMPR(cfg, P["embedding.weight"].numpy())
+        m.load_state_dict(P)
+        m = m.to(dev)
+        return m, FusedAdam(m, 1e-3, 1e-3, lr_decay=0.99)
+
+    m1, o1 = fresh()
+    for b in batches:
+        train_step(m1, o1, b)
+    m2, o2 = fresh()
+    for b in batches[:2]:
+        train_step(m2, o2, b)
+    path = str(tmp_path / "ck.pt")
+    save_checkpoint(path, m2, o2, epoch=0, batch_counter=2)
+    m3, o3 = fresh()
+    meta = load_checkpoint(path, m3, o3, map_location=dev)
+    assert meta["batch_counter"] == 2
+    for b in batches[2:]:
+        train_step(m3, o3, b)
+    for (k, a), (_, c) in zip(m1.state_dict().items(), m3.state_dict().items()):
+        assert torch.equal(a, c), k
+
+
+def test_main_cli_on_csv_corpus(tmp_path, capsys, monkeypatch):
+    """main.py --data_dir <reference-layout dir> trains and reports a test MSE (readme.md:70-92).  Run in-process (argv
+    patched): a GPU-initialised test process must not fork+exec another GPU program on this pool."""
+    import importlib
+    d = tmp_path / "music"
+    d.mkdir()
+    for split in ("train", "valid", "test"):
+        shutil.copy(os.path.join(CORPUS, "train.csv"), d / f"{split}.csv")
+    shutil.copy(os.path.join(CORPUS, "photos.json"), d / "photos.json")
+    (d / "photos").mkdir()
+    argv = ["main.py", "--data_dir", str(d), "--word2vec_file", os.path.join(CORPUS, "glove.txt"),
+            "--review_net_only", "True", "--train_epochs", "2", "--batch_size", "4", "--max_sent_count", "6",
+            "--min_sent_count", "2", "--max_ui_sent_count", "3", "--max_sent_length", "10", "--views", "food",
+            "--learning_rate", "1e-3", "--model_path", str(tmp_path / "m.pt")]
+    monkeypatch.setattr(sys, "argv", argv)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.chdir(tmp_path)
+    main = importlib.import_module("main")
+    main.main()
+    out = capsys.readouterr().out
+    assert "Initial validation mse is" in out and "Test end, test mse is" in out, out[-2000:]
+    mse = float(out.strip().split("test mse is")[-1])
+    assert mse == mse and mse < 100.0
+
+
+@pytest.mark.parametrize("review_net_only", [True, False])
+def test_training_is_bitwise_reproducible(dev, review_net_only):
+    """Two fresh model/optimiser instances driven through the same steps end with identical bits in every parameter
+    (no float atomics, fixed-order reductions, dropout mask a pure function of (seed, step, index))."""
+    from umpr_amd.model import UMPR
+    from umpr_amd.optim import FusedAdam
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import train_step
+    P = make_param_state(121, 50, 500, 1, review_net_only, m_scale=0.05)
+    cfg = _cfg(review_net_only=review_net_only, views=["unknown"])
+    batches = [make_batch(130 + i, 3, 500, 1, review_net_only=review_net_only) for i in range(3)]
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        m = UMPR(cfg, P["embedding.weight"].numpy())
+        m.load_state_dict(P)
+        m = m.to(dev)
+        opt = FusedAdam(m, 1e-3, 1e-3)
+        losses = [train_step(m, opt, b)[1].item() for b in batches]
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k

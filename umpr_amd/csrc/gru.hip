@@ -145,7 +145,6 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
   __shared__ float Ws[G3 * H];     // Ws[gate][hid] = W_hh (natural layout)
   __shared__ float DG[G3 * LDG];   // DG[gate][seq]
   __shared__ float HP[TS * H];     // HP[seq][hid] = h_{prev}
-  __shared__ float sb[2 * G3];
   __shared__ int s_n[TS], s_len[TS], s_dst[TS];
   __shared__ int s_maxlen;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,7 +167,6 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
     atomicMax(&s_maxlen, len);
   }
   for (int e = tid; e < G3 * H; e += 256) Ws[e] = p.whh[dir][e];
-  for (int e = tid; e < 2 * G3; e += 256) sb[e] = 0.f;
   __syncthreads();
   const int maxlen = s_maxlen;
   const int hid = wh * 32 + l31;
@@ -265,14 +263,21 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) slab[(gt * 32 + mfma_row(r, lane)) * H + ht * 32 + l31] = accw[i][r];
   }
+  // bias gradients: 4 threads (2 sequence halves x 2 lane halves) hold partial sums for each (gate, hid).  Summed in
+  // a fixed order through LDS (DG is free after the loop's last barrier) - float atomics would make the result depend
+  // on arrival order.
+  {
+    float* part = DG + (ws * 2 + kh) * (2 * G3);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    atomicAdd(&sb[q * H + hid], sbi[q]);
-    atomicAdd(&sb[G3 + q * H + hid], sbh[q]);
+    for (int q = 0; q < 3; ++q) {
+      part[q * H + hid] = sbi[q];
+      part[G3 + q * H + hid] = sbh[q];
+    }
   }
   __syncthreads();
   float* bs = p.dbias_slab + ((long)tile * 2 + dir) * 2 * G3;
-  for (int e = tid; e < 2 * G3; e += 256) bs[e] = sb[e];
+  for (int e = tid; e < 2 * G3; e += 256)
+    bs[e] = ((DG[e] + DG[2 * G3 + e]) + DG[4 * G3 + e]) + DG[6 * G3 + e];
 }
 
 // dst[j] (+)= sum_i src[i][j]   (rows x cols, fixed order)
