@@ -141,13 +141,13 @@ def main():
     model.load_state_dict(P)
     model = model.to(dev)
     opt = FusedAdam(model, cfg.learning_rate, cfg.l2_regularization, cfg.lr_decay)
-    reducer = parallel.GradReducer(opt) if world > 1 else None
+    reducer = parallel.GradReducer(opt) if parallel.active() else None
     batch = to_device(make_batch(1234 + rank, args.batch, args.vocab, args.views, review_net_only=args.review_net_only,
                                  full_pad=not args.realistic), dev)
     loss_sum = torch.zeros((), device=dev)
 
     def barrier():
-        if world > 1:
+        if parallel.active():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -166,7 +166,7 @@ def main():
     dt = time.perf_counter() - t0
     L.fn["umpr_profile_enable"](0)
     note(f"{args.steps} steps in {dt:.3f} s")
-    if world > 1:
+    if parallel.active():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -209,7 +209,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, P, rank)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if parallel.active():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

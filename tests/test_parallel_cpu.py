@@ -92,6 +92,23 @@ def test_shard_batch_matches_chunk():
                 assert torch.equal(parts[r][i], ref[r])
 
 
+class _JointClassifier(torch.autograd.Function):
+    """Both linear layers in ONE backward node, like umpr_amd.model._VGGClassifier: all weight gradients are returned
+    together, so autograd runs their AccumulateGrad nodes in an order the reducer must not rely on."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        h = torch.tanh(x @ w1.t() + b1)
+        ctx.save_for_backward(x, w1, w2, h)
+        return h @ w2.t() + b2
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, h = ctx.saved_tensors
+        dh = (dy @ w2) * (1 - h * h)
+        return dh @ w1, dh.t() @ x, dh.sum(0), dy.t() @ h, dy.sum(0)
+
+
 class _Tiny(torch.nn.Module):
     """Parameter names shaped like the real model: a 'classifier' part whose gradients come first, a conv-like rest."""
 
@@ -101,7 +118,8 @@ class _Tiny(torch.nn.Module):
         self.classifier = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
 
     def forward(self, x):
-        return self.classifier(self.features(x))
+        c = self.classifier
+        return _JointClassifier.apply(self.features(x), c[0].weight, c[0].bias, c[2].weight, c[2].bias)
 
 
 def _reducer_worker(rank, world, port, out):
@@ -115,7 +133,7 @@ def _reducer_worker(rank, world, port, out):
     model = _Tiny()
     opt = FusedAdam(model, 1e-3, 1e-3)
     red = parallel.GradReducer(opt, n_buckets=3)
-    assert red.early is not None and red.hook is not None
+    assert red.early is not None and len(red.hooks) == 2
     names0 = opt.groups[0].names
     assert "classifier." in names0[0] and "classifier." not in names0[-1], names0  # classifier slice leads the arena
     g = torch.Generator().manual_seed(100 + rank)

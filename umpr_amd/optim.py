@@ -105,13 +105,14 @@ class FusedAdam:
         return [g.g for g in self.groups if g.numel]
 
     def early_bucket(self):
-        """(arena, lo, hi, trigger parameter) of the classifier-weight slice of the weight arena, or None.  The trigger
-        is the parameter whose gradient is accumulated last among them (fc1: backward runs fc3 -> fc2 -> fc1)."""
+        """(arena, lo, hi, parameters) of the classifier-weight slice of the weight arena, or None.  The slice is
+        complete once every one of `parameters` has had its gradient accumulated (one backward node returns all of
+        them, and autograd does not promise an order among their AccumulateGrad nodes)."""
         g = self.groups[0]
         names = [n for n in g.names if _is_classifier(n)]
         if not names:
             return None
         lo = min(g.offsets[n][0] for n in names)
         hi = max(g.offsets[n][0] + g.offsets[n][1] for n in names)
-        trig = [p for n, p in zip(g.names, g.params) if n.endswith("classifier.0.weight")]
-        return (g.g, lo, hi, trig[0]) if trig else None
+        params = [p for n, p in zip(g.names, g.params) if n in set(names)]
+        return (g.g, lo, hi, params)

@@ -17,12 +17,22 @@ import torch
 import torch.distributed as dist
 
 
+def _force():
+    """UMPR_REDUCE_AT_WORLD1=1: run the whole exchange path (RCCL init, overlapped all-reduce) with a single rank -
+    the rehearsal a one-GPU box allows."""
+    return os.environ.get("UMPR_REDUCE_AT_WORLD1", "") == "1"
+
+
+def active():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _force())
+
+
 def init_distributed(backend=None):
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and join the process group."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -44,7 +54,7 @@ def shard_batch(batch, rank, world):
 def allreduce_arenas(arenas, n_buckets=4):
     """Sum the flat gradient arenas over all ranks (in place).  Returns after the collectives are enqueued on the
     current stream (RCCL orders them with the following Adam kernel)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return
     for a in arenas:
         if a.numel() > (1 << 22) and n_buckets > 1:
@@ -56,7 +66,7 @@ def allreduce_arenas(arenas, n_buckets=4):
 
 def allreduce_scalars(values, device):
     t = torch.tensor(values, dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.tolist()
 
@@ -64,10 +74,11 @@ def allreduce_scalars(values, device):
 class GradReducer:
     """Gradient exchange for one training step, overlapped with backward.
 
-    The weight-gradient arena starts with the VGG classifier slice (FusedAdam's ordering).  A post-accumulate hook on
-    fc1.weight - the last classifier gradient autograd produces - launches the all-reduce of that slice asynchronously
-    (RCCL runs on its own stream), so 494 MB of the 554 MB travel over xGMI while the convolutional backward is still
-    computing; `finish()` reduces the remainder and waits.  Sum only: the 1/world scale is folded into the Adam kernel."""
+    The weight-gradient arena starts with the VGG classifier slice (FusedAdam's ordering).  Post-accumulate hooks on
+    the classifier weights - the first gradients autograd produces - count down; when the last of them has landed the
+    all-reduce of that slice is launched asynchronously (RCCL runs on its own stream), so 494 MB of the 554 MB travel
+    over xGMI while the convolutional backward is still computing; `finish()` reduces the remainder and waits.
+    Sum only: the 1/world scale is folded into the Adam kernel."""
 
     def __init__(self, opt, n_buckets=4):
         self.opt = opt
@@ -75,18 +86,25 @@ class GradReducer:
         self.handles = []
         self.early = opt.early_bucket() if hasattr(opt, "early_bucket") else None
         self.fired = False
-        self.hook = None
-        if self.early is not None and dist.is_initialized() and dist.get_world_size() > 1:
-            self.hook = self.early[3].register_post_accumulate_grad_hook(self._fire)
+        self.pending = 0
+        self.hooks = []
+        if self.early is not None and active():
+            self.pending = len(self.early[3])
+            self.hooks = [p.register_post_accumulate_grad_hook(self._landed) for p in self.early[3]]
 
-    def _fire(self, _param=None):
+    def _landed(self, _param=None):
+        self.pending -= 1
+        if self.pending == 0:
+            self._fire()
+
+    def _fire(self):
         arena, lo, hi, _ = self.early
         for chunk in torch.chunk(arena[lo:hi], self.n_buckets):
             self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
         self.fired = True
 
     def finish(self):
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not active():
             return
         arenas = self.opt.grad_arenas()
         if self.fired:
@@ -101,3 +119,4 @@ class GradReducer:
             h.wait()
         self.handles = []
         self.fired = False
+        self.pending = len(self.early[3]) if self.hooks else 0

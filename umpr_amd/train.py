@@ -33,7 +33,7 @@ def train_step(model, opt: FusedAdam, batch, world=1, reducer=None):
     loss = loss.mean()
     opt.zero_grad()
     loss.backward()
-    if world > 1:
+    if world > 1 or reducer is not None:
         if reducer is not None:
             reducer.finish()
         else:
@@ -48,7 +48,7 @@ def training(train_dataloader, valid_dataloader, model, config, model_path, logg
     log(f'Initial validation mse is {valid_mse:.6f}')
     start = time.perf_counter()
     opt = FusedAdam(model, config.learning_rate, config.l2_regularization, config.lr_decay)
-    reducer = parallel.GradReducer(opt) if world > 1 else None
+    reducer = parallel.GradReducer(opt) if parallel.active() else None
     best_loss, batch_counter, first_epoch = 100, 0, 0
     resume = getattr(config, "resume", "")
     if resume:  # not in the reference (it keeps no optimiser / epoch state): exact resume from umpr_amd.checkpoint
