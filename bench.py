@@ -116,6 +116,12 @@ def cpu_baseline(args, P, rank):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when the first
+    # communicator is created, so everything but the result line is sent to stderr: fd 1 is pointed at fd 2 and the
+    # JSON goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     from umpr_amd import parallel
     from umpr_amd._lib import lib
     from umpr_amd.config import Config
@@ -208,7 +214,8 @@ def main():
             out["model_tflops"] = value * GFLOP_PER_SAMPLE_TRAIN / 1e3 / world
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, P, rank)
-        print(json.dumps(out), flush=True)
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if parallel.active():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
