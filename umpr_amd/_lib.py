@@ -127,13 +127,14 @@ def stream_ptr() -> int:
 
 
 class Workspace:
-    """One growing scratch buffer per device.  Ops on one stream are serialised, so they can share it; nothing in
-    it is live between two C-ABI calls."""
+    """One growing scratch buffer per (device, stream).  Ops on one stream are serialised, so they can share it;
+    nothing in it is live between two C-ABI calls.  Two streams never share a buffer (the text path and the VGG path of
+    UMPR.forward run concurrently)."""
     _bufs = {}
 
     @classmethod
     def get(cls, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         buf = cls._bufs.get(key)
         if buf is None or buf.numel() * 4 < nbytes:
             buf = None

@@ -11,12 +11,15 @@ Reference lines: UMPR.__init__ src/model.py:233-255, UMPR.forward src/model.py:2
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 from torch import nn
 
 from ._lib import Workspace, lib, stream_ptr
 
+TEXT_STREAM = os.environ.get("UMPR_TEXT_STREAM", "1") != "0"   # text path on a side stream beside the VGG stack
+_SIDE_STREAMS = {}
 H = 64          # config.gru_size the kernels are built for
 D = 2 * H
 AT = 64         # config.self_atte_size
@@ -495,6 +498,32 @@ class UMPR(nn.Module):
         both = both.to(device, non_blocking=True)
         return both[0], both[1]
 
+    @staticmethod
+    def _side_stream(device):
+        st = _SIDE_STREAMS.get(device)
+        if st is None:
+            st = _SIDE_STREAMS[device] = torch.cuda.Stream(device)
+        return st
+
+    def _review(self, user_reviews, item_reviews, lu, ou, li, oi, emb):
+        B, S, L = user_reviews.shape
+        rn = self.review_net
+        gru_u = rn.r_net.gru(user_reviews.view(B * S, L), lu, ou, emb).view(B, S * L, D)
+        gru_i = rn.r_net.gru(item_reviews.view(B * S, L), li, oi, emb).view(B, S * L, D)
+        return _ReviewHead.apply(gru_u, gru_i, S, L, rn.r_net.M, rn.s_net_u.Ms, rn.s_net_u.Ws, rn.s_net_i.Ms,
+                                 rn.s_net_i.Ws, rn.linear_u.weight, rn.linear_i.weight)
+
+    def _control(self, user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui, emb):
+        B, S, L = user_reviews.shape
+        _, S_ui, L_ui = ui_reviews.shape
+        cn = self.control_net
+        c_ui = cn.c_net.gru(ui_reviews.view(B * S_ui, L_ui), lui, oui, emb).view(B, S_ui * L_ui, D)
+        c_u = cn.c_net.gru(user_reviews.view(B * S, L), lu, ou, emb).view(B, S * L, D)
+        c_i = cn.c_net.gru(item_reviews.view(B * S, L), li, oi, emb).view(B, S * L, D)
+        return _Control.apply(c_ui, c_u, c_i, (B, S_ui, L_ui, S, L), cn.c_net.threshold, cn.c_net.cnn[0].weight,
+                              cn.c_net.cnn[0].bias, cn.c_net.linear[0].weight, cn.c_net.linear[0].bias, cn.s_net.Ms,
+                              cn.s_net.Ws, cn.ss_net.linear[0].weight, cn.ss_net.linear[0].bias)
+
     def forward(self, user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels):
         device = self.embedding.weight.device
         if device.type != "cuda":
@@ -507,29 +536,35 @@ class UMPR(nn.Module):
         _, S_ui, L_ui = ui_reviews.shape
         lu, ou = self._host_perm(u_lengths, device)
         li, oi = self._host_perm(i_lengths, device)
-        rn = self.review_net
-        gru_u = rn.r_net.gru(user_reviews.view(B * S, L), lu, ou, emb).view(B, S * L, D)
-        gru_i = rn.r_net.gru(item_reviews.view(B * S, L), li, oi, emb).view(B, S * L, D)
-        rr = _ReviewHead.apply(gru_u, gru_i, S, L, rn.r_net.M, rn.s_net_u.Ms, rn.s_net_u.Ws, rn.s_net_i.Ms,
-                               rn.s_net_i.Ws, rn.linear_u.weight, rn.linear_i.weight)
         fus = self.linear_fusion[0]
         if self.review_net_only:
+            rr = self._review(user_reviews, item_reviews, lu, ou, li, oi, emb)
             pred, loss, terms = _Head.apply(rr, None, None, None, None, None, None, None, None, None, fus.weight,
                                             fus.bias, labels, 0.0, 0, 0)
             self.last_loss_terms = terms
             return pred, loss
-        cn = self.control_net
         lui, oui = self._host_perm(ui_lengths, device)
-        c_ui = cn.c_net.gru(ui_reviews.view(B * S_ui, L_ui), lui, oui, emb).view(B, S_ui * L_ui, D)
-        c_u = cn.c_net.gru(user_reviews.view(B * S, L), lu, ou, emb).view(B, S * L, D)
-        c_i = cn.c_net.gru(item_reviews.view(B * S, L), li, oi, emb).view(B, S * L, D)
-        cu, ci, pp, pn = _Control.apply(c_ui, c_u, c_i, (B, S_ui, L_ui, S, L), cn.c_net.threshold,
-                                        cn.c_net.cnn[0].weight, cn.c_net.cnn[0].bias, cn.c_net.linear[0].weight,
-                                        cn.c_net.linear[0].bias, cn.s_net.Ms, cn.s_net.Ws, cn.ss_net.linear[0].weight,
-                                        cn.ss_net.linear[0].bias)
+        # The text path (many small, latency-bound kernels: GRUs, co-attention, heads) runs on a side stream beside the
+        # VGG stack (MFMA-bound) and joins it at the head; autograd replays the same split in backward.
+        main = torch.cuda.current_stream(device)
+        side = self._side_stream(device) if TEXT_STREAM else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rr = self._review(user_reviews, item_reviews, lu, ou, li, oi, emb)
+                cu, ci, pp, pn = self._control(user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui, emb)
+            for t in (user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui):
+                t.record_stream(side)
+        else:
+            rr = self._review(user_reviews, item_reviews, lu, ou, li, oi, emb)
+            cu, ci, pp, pn = self._control(user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui, emb)
         vn = self.visual_net
         V, Pc = photos.shape[1], photos.shape[2]
         vgg = vn.vgg16[0](photos.reshape(B * V * Pc, *photos.shape[3:]).float())
+        if side is not None:
+            main.wait_stream(side)
+            for t in (rr, cu, ci, pp, pn):
+                t.record_stream(main)
         pred, loss, terms = _Head.apply(rr, cu, ci, pp, pn, vgg, vn.pos_v_emb, vn.neg_v_emb, vn.linear.weight,
                                         vn.linear.bias, fus.weight, fus.bias, labels, self.loss_v_rate, V, Pc)
         self.last_loss_terms = terms
