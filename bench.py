@@ -31,16 +31,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 
 GFLOP_PER_SAMPLE_TRAIN = 93.73  # SURVEY.md 8(d), cfg2 fully padded
 
 
-def pmc_traffic(launches_per_step):
-    """HBM-side bytes per launch of the conv forward+dgrad family from the committed rocprofv3 --pmc passes of this
-    build (profiles/README.md; FETCH_SIZE doubled per the guide's gfx950 correction).  bench.py cannot run the
+def pmc_traffic():
+    """HBM-side bytes per launch of the conv forward/dgrad kernels from the committed rocprofv3 --pmc passes of this
+    build (profiles/README.md; FETCH_SIZE doubled per the guide's gfx950 correction), averaged over the 25 forward +
+    dgrad layer calls of a step (the same kernels; the counters are summed per kernel name).  bench.py cannot run the
     counter passes itself, so the figure is the stored measurement, or None when the file is absent."""
     path = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
     try:
         d = json.load(open(path))
         f = d["families"]["igemm_family"]
         per_step = (2.0 * f["FETCH_SIZE"] + f["WRITE_SIZE"]) * 1024.0 / d["steps"]
-        return per_step / max(launches_per_step, 1), "bytes/launch from profiles/r01_e_pmc_traffic.json (batch 64 run)"
+        return per_step / 25.0, "bytes/launch from profiles/r01_e_pmc_traffic.json (batch 64, 25 fwd+dgrad launches/step)"
     except Exception:
         return None, "no stored PMC pass"
 
@@ -178,18 +179,19 @@ def main():
         dt = float(t.item())
 
     fam = {}
-    for name, idx in (("conv3x3_igemm", 0), ("conv3x3_wgrad", 1), ("gemm_f32", 2), ("wino_gemm", 4)):
+    for name, idx in (("conv3x3_fwd", 0), ("conv3x3_dgrad", 5), ("conv3x3_wgrad", 1), ("gemm_f32", 2), ("wino_gemm", 4)):
         ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
         L.fn["umpr_profile_read"](idx, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
         fam[name] = (ms.value, work.value, n.value)
 
     if rank == 0:
         value = world * args.batch * args.steps / dt
-        ms, work, n = fam["conv3x3_igemm"]
+        ms, work, n = fam["conv3x3_fwd"]
         achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # Winograd layers execute 1/2.25 of the direct-convolution FLOPs `achieved` counts for them
-        executed = (work - 1.25 * fam["wino_gemm"][1]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_note = pmc_traffic(n / max(args.steps, 1))
+        # Winograd layers execute 1/2.25 of the direct-convolution FLOPs `achieved` counts for them;
+        # the same nine layers take the Winograd path in forward and in dgrad, so half of family 4's work is forward
+        executed = (work - 1.25 * 0.5 * fam["wino_gemm"][1]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic() if args.batch == 64 and not args.review_net_only else (None, "stored PMC pass is for batch 64")
         out = {
             "metric": "training samples/sec", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -203,8 +205,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": traffic_note, "executed_tflops": executed,
-                         "kernel": "conv3x3 forward + dgrad family (direct implicit GEMM on 224/112 maps, Winograd "
-                                   "F(2x2,3x3) transforms + batched GEMM on 56/28/14 maps)", "launches": n,
+                         "kernel": "conv3x3 forward family (conv3x3_igemm_v2_kernel on 224/112 maps; wino_input / "
+                                   "wino_gemm / wino_output kernels, Winograd F(2x2,3x3), on 56/28/14 maps); its dgrad "
+                                   "and wgrad launches overlap on two streams and are listed under kernels", "launches": n,
                          "avg_launch_ms": ms / max(n, 1), "algorithmic_gflop_per_launch": work / max(n, 1) / 1e9},
             "kernels": {k: {"ms_per_step": v[0] / args.steps, "tflops": (v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0),
                             "launches_per_step": v[2] / args.steps} for k, v in fam.items()},

@@ -286,9 +286,9 @@ static size_t wt_floats(int n) { return vgg_scratch_bytes(n) / sizeof(float); }
 size_t umpr_vgg16_fwd_ws_bytes(int n_img) { return vgg_scratch_bytes(n_img); }
 
 size_t umpr_vgg16_ws_bytes(int n_img) {
-  // [d_pool5][gradient ping][gradient pong] (largest activation each) [packed weights][scratch]
+  // [d_pool5][3 rotating gradient slots] (largest activation each) [packed weights][scratch]
   const size_t big = (size_t)n_img * 64 * 224 * 224;
-  return ((size_t)n_img * 25088 + 2 * big + wt_floats(n_img)) * sizeof(float) + vgg_scratch_bytes(n_img);
+  return ((size_t)n_img * 25088 + 3 * big + wt_floats(n_img)) * sizeof(float) + vgg_scratch_bytes(n_img);
 }
 
 size_t umpr_conv3x3_pack_bytes(int N, int Cin, int Cout, int H_, int W) {
@@ -419,8 +419,30 @@ int umpr_vgg16_classifier_bwd(const float* const* params, int n, int train, cons
 
 size_t umpr_vgg16_features_bwd_ws_bytes(int n_img) {
   const size_t big = (size_t)n_img * 64 * 224 * 224;
-  return (2 * big + wt_floats(n_img)) * sizeof(float) + vgg_scratch_bytes(n_img);
+  return (3 * big + wt_floats(n_img)) * sizeof(float) + vgg_scratch_bytes(n_img);
 }
+
+// Library-owned side stream for the weight-gradient kernels of the VGG backward (one per process: one GPU per process).
+namespace {
+struct WgradSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t ready[13] = {};   // recorded on the caller's stream: gradient of layer ci is complete
+  hipEvent_t done[13] = {};    // recorded on the side stream: wgrad of layer ci has finished reading it
+  bool ok = false;
+  bool init() {
+    if (ok) return true;
+    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 13; ++i) {
+      if (hipEventCreateWithFlags(&ready[i], hipEventDisableTiming) != hipSuccess) return false;
+      if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    ok = true;
+    return true;
+  }
+};
+WgradSide g_wside;
+const bool g_wgrad_side = [] { const char* v = getenv("UMPR_WGRAD_STREAM"); return !(v && v[0] == '0'); }();
+}  // namespace
 
 int umpr_vgg16_features_bwd(const float* images, const float* const* params, int n, const float* acts,
                             const float* d_pool5, float* const* grads, float* ws, size_t ws_bytes, void* stream) {
@@ -428,34 +450,58 @@ int umpr_vgg16_features_bwd(const float* images, const float* const* params, int
   const VggLayout L = vgg_layout(n);
   hipStream_t s = S(stream);
   const size_t big = (size_t)n * 64 * 224 * 224;
-  float* gA = ws;
-  float* gB = ws + big;
-  float* wt = gB + big;
+  float* buf[3] = {ws, ws + big, ws + 2 * big};
+  float* wt = buf[2] + big;
   float* scratch = wt + wt_floats(n);
   const size_t slab_bytes = vgg_scratch_bytes(n);
+  // The weight gradient of a layer depends only on that layer's output gradient, not on the data-gradient chain that
+  // continues below it: it runs on a side stream, so that its MFMA work fills the HBM-bound phases of the chain
+  // (pool backward, Winograd transforms) on the caller's stream.  The gradient buffers rotate through three slots:
+  // a slot is rewritten two layers after it was produced, behind a wait for the wgrad that read it.
+  const bool side = g_wgrad_side && g_wside.init();
+  hipStream_t sw = side ? g_wside.stream : s;
+  int slot_reader[3] = {-1, -1, -1};   // layer whose side-stream wgrad still reads the slot
+  int nxt = 0;
+  auto claim = [&]() -> float* {       // next slot to write on the caller's stream
+    const int k = nxt; nxt = (nxt + 1) % 3;
+    if (side && slot_reader[k] >= 0) { (void)hipStreamWaitEvent(s, g_wside.done[slot_reader[k]], 0); slot_reader[k] = -1; }
+    return buf[k];
+  };
   const float* g = d_pool5;
-  float* cur = gA; float* oth = gB;
-  // last block first.  (Tried: wgrad on a side stream so that its grid fills the tail of the dgrad grid - no gain at
-  // batch 64, 67.4 vs 67.2 ms/step, and per-kernel event timing loses meaning under overlap; dropped.)
+  int gslot = -1;                      // slot index holding g (-1: the caller's d_pool5)
   int ci = 12;
   for (int b = 4; b >= 0; --b) {
     const int hw = L.conv_hw[ci];
     // pool backward + ReLU mask of the conv output feeding it -> gradient w.r.t. the conv pre-activation
+    float* cur = claim();
     if (int rc = umpr_maxpool2_bwd_relu_impl(acts + L.conv_off[ci], g, cur, (long)n * kBlockCh[b], hw, hw, s)) return rc;
-    g = cur; { float* t = cur; cur = oth; oth = t; }
+    g = cur; gslot = (nxt + 2) % 3;
     for (int j = kConvPerBlock[b] - 1; j >= 0; --j, --ci) {
       const int cin = L.conv_cin[ci], cout = L.conv_cout[ci];
       const float* xin = ci == 0 ? images : (j == 0 ? acts + L.pool_off[b - 1] : acts + L.conv_off[ci - 1]);
+      if (side) {
+        (void)hipEventRecord(g_wside.ready[ci], s);
+        (void)hipStreamWaitEvent(sw, g_wside.ready[ci], 0);
+      }
       if (int rc = umpr_conv3x3_wgrad(g, xin, grads[2 * ci], grads[2 * ci + 1], n, cin, cout, hw, hw, 0, scratch,
-                                      slab_bytes, s)) return rc;
+                                      slab_bytes, sw)) return rc;
+      if (side) {
+        (void)hipEventRecord(g_wside.done[ci], sw);
+        slot_reader[gslot] = ci;
+      }
       if (ci == 0) break;
       // input came straight from a conv+ReLU (j > 0): mask by it; from a pool (j == 0): the pool backward masks
       const float* mask = j > 0 ? xin : nullptr;
+      cur = claim();
       if (int rc = umpr_conv3x3_run(g, params[2 * ci], 1, nullptr, mask, cur, n, cin, cout, hw, hw, 0, wt, wt_floats(n), s))
         return rc;
-      g = cur; { float* t = cur; cur = oth; oth = t; }
+      g = cur; gslot = (nxt + 2) % 3;
     }
     if (ci == 0 && b == 0) break;
+  }
+  if (side) {  // the caller's stream owns the results again: every weight gradient is complete behind this wait
+    hipEvent_t& last = g_wside.done[0];
+    (void)hipStreamWaitEvent(s, last, 0);
   }
   return 0;
 }

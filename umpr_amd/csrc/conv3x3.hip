@@ -1024,7 +1024,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
   if (wino_layer(H, W) && !g_conv_no_wino && !g_conv_force_v1 && wpack && C >= 32 &&
       wpack_floats >= umpr_wino_ws_floats(N, C, M, H, W)) {
     // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs; timed under the same family with the direct conv's FLOP count
-    UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
+    UmprProfScope prof(transposed ? UMPR_K_CONV_DGRAD : UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
     return umpr_wino_conv3x3(x, w, transposed, bias, mask, y, N, Cin, Cout, H, W, relu, wpack, wpack_floats, s);
   }
   const bool v2 = H == W && !g_conv_force_v1 && wpack && (W == 224 || W == 112 || W == 56 || W == 28 || W == 14);
@@ -1036,7 +1036,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
     pack_weights_kernel<<<blocks, 256, 0, s>>>(w, wpack, M, C, Cin, transposed);
     UMPR_LAUNCH_CHECK("pack_weights");
     ConvParams p{x, wpack, bias, mask, y, N, C, H, W, M, relu, 0, NP};
-    UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
+    UmprProfScope prof(transposed ? UMPR_K_CONV_DGRAD : UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
     if (W == 224) launch_v2<224>(p, g_conv_bn, s);
     else if (W == 112) launch_v2<112>(p, g_conv_bn, s);
     else if (W == 56) launch_v2<56>(p, g_conv_bn, s);
@@ -1052,7 +1052,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
     wm = wpack;
   }
   ConvParams p{x, wm, bias, mask, y, N, C, H, W, M, relu, 0, NP};
-  UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
+  UmprProfScope prof(transposed ? UMPR_K_CONV_DGRAD : UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
   if (M <= 64) {
     dim3 grid(cdiv(NP, 128), cdiv(M, 64));
     conv3x3_igemm_kernel<64, 128><<<grid, 256, 0, s>>>(p);

@@ -125,7 +125,8 @@ int umpr_gate_bwd_impl(const float* sa, const float* w, const float* view_p, con
 // one family while profiling is enabled.  Zero cost when disabled.
 enum UmprKernelFamily { UMPR_K_CONV_IGEMM = 0, UMPR_K_CONV_WGRAD = 1, UMPR_K_GEMM = 2, UMPR_K_GRU = 3,
                         UMPR_K_WINO_GEMM = 4 /* nested inside CONV_IGEMM: executed MFMA FLOPs of the Winograd GEMM */,
-                        UMPR_K_COUNT = 5 };
+                        UMPR_K_CONV_DGRAD = 5 /* the conv kernels of family 0 run as data gradient */,
+                        UMPR_K_COUNT = 6 };
 struct UmprProfScope {
   UmprProfScope(int family, double work, hipStream_t s);
   ~UmprProfScope();
