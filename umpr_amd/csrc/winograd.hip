@@ -114,6 +114,64 @@ __global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict
   }
 }
 
+// Same transform, two horizontally adjacent tiles per thread (even tile rows only: 56x56 and 28x28 maps): the six
+// input columns the pair touches are loaded as scalar | float2 | float2 | scalar per row (half the load and store
+// instructions of the one-tile kernel), and the results leave as float2.
+__global__ void wino_input_pair_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int Cpad,
+                                       int H, int W, long Tpad, long Tw) {
+  const int TH = H / 2, TW = W / 2;
+  const long T = (long)N * TH * TW;
+  const long Tw2 = Tw / 2;
+  const long total = (long)Cpad * Tw2;
+  const long per = (long)Cpad * Tpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = 2 * (i % Tw2);
+    const int c = (int)(i / Tw2);
+    float* dst = V + (long)c * Tpad + t;
+    if (t >= T || c >= C) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) *reinterpret_cast<float2*>(dst + (long)a * per) = make_float2(0.f, 0.f);
+      continue;
+    }
+    const int tx = (int)(t % TW);   // even; tx + 1 is in the same tile row
+    const long r = t / TW;
+    const int ty = (int)(r % TH), n = (int)(r / TH);
+    const float* src = x + ((long)n * C + c) * H * W;
+    const int x0 = 2 * tx;
+    const bool okl = x0 > 0, okr = x0 + 4 < W;
+    float d[4][6];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int yy = 2 * ty - 1 + a;
+      const bool oky = yy >= 0 && yy < H;
+      const float* row = src + (oky ? yy * W + x0 : x0);
+      const float l = row[okl ? -1 : 0];
+      const float2 m0 = *reinterpret_cast<const float2*>(row);
+      const float2 m1 = *reinterpret_cast<const float2*>(row + 2);
+      const float rr = row[okr ? 4 : 0];
+      d[a][0] = oky && okl ? l : 0.f;
+      d[a][1] = oky ? m0.x : 0.f; d[a][2] = oky ? m0.y : 0.f;
+      d[a][3] = oky ? m1.x : 0.f; d[a][4] = oky ? m1.y : 0.f;
+      d[a][5] = oky && okr ? rr : 0.f;
+    }
+    float bd[4][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      bd[0][b] = d[0][b] - d[2][b];
+      bd[1][b] = d[1][b] + d[2][b];
+      bd[2][b] = d[2][b] - d[1][b];
+      bd[3][b] = d[1][b] - d[3][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {   // tile 0 uses columns 0..3, tile 1 columns 2..5
+      *reinterpret_cast<float2*>(dst + (long)(a * 4 + 0) * per) = make_float2(bd[a][0] - bd[a][2], bd[a][2] - bd[a][4]);
+      *reinterpret_cast<float2*>(dst + (long)(a * 4 + 1) * per) = make_float2(bd[a][1] + bd[a][2], bd[a][3] + bd[a][4]);
+      *reinterpret_cast<float2*>(dst + (long)(a * 4 + 2) * per) = make_float2(bd[a][2] - bd[a][1], bd[a][4] - bd[a][3]);
+      *reinterpret_cast<float2*>(dst + (long)(a * 4 + 3) * per) = make_float2(bd[a][1] - bd[a][3], bd[a][3] - bd[a][5]);
+    }
+  }
+}
+
 // y[n][m][2ty+i][2tx+j] = epilogue( (A^T M A)[i][j] ),  A^T = [1 1 1 0; 0 1 -1 -1]
 __global__ void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
                                    const float* __restrict__ mask, float* __restrict__ y, int N, int Mch, int H,
@@ -158,6 +216,64 @@ __global__ void wino_output_kernel(const float* __restrict__ Mx, const float* __
         v0 = mk.x > 0.f ? v0 : 0.f; v1 = mk.y > 0.f ? v1 : 0.f;
       }
       *reinterpret_cast<float2*>(y + oo) = make_float2(v0, v1);
+    }
+  }
+}
+
+// Two horizontally adjacent tiles per thread (even tile rows): float2 loads of M, float4 stores of y.
+__global__ void wino_output_pair_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
+                                        const float* __restrict__ mask, float* __restrict__ y, int N, int Mch, int H,
+                                        int W, long Tpad, int Mpad, int relu) {
+  const int TH = H / 2, TW = W / 2;
+  const long T2 = (long)N * TH * TW / 2;
+  const long total = (long)Mch * T2;
+  const long per = (long)Mpad * Tpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = 2 * (i % T2);
+    const int m = (int)(i / T2);
+    const int tx = (int)(t % TW);
+    const long r = t / TW;
+    const int ty = (int)(r % TH), n = (int)(r / TH);
+    const float* src = Mx + (long)m * Tpad + t;
+    float2 mm[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) mm[a][b] = *reinterpret_cast<const float2*>(src + (long)(a * 4 + b) * per);
+    float o[2][4];   // [output row][4 consecutive output columns: tile 0 cols 0,1 | tile 1 cols 0,1]
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float am[2][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float m0 = q ? mm[0][b].y : mm[0][b].x, m1 = q ? mm[1][b].y : mm[1][b].x;
+        const float m2 = q ? mm[2][b].y : mm[2][b].x, m3 = q ? mm[3][b].y : mm[3][b].x;
+        am[0][b] = m0 + m1 + m2;
+        am[1][b] = m1 - m2 - m3;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        o[a][2 * q + 0] = am[a][0] + am[a][1] + am[a][2];
+        o[a][2 * q + 1] = am[a][1] - am[a][2] - am[a][3];
+      }
+    }
+    const float bv = bias ? bias[m] : 0.f;
+    const long ob = (((long)n * Mch + m) * H + 2 * ty) * W + 2 * tx;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = o[a][j] + bv;
+        if (relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      const long oo = ob + (long)a * W;
+      if (mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(mask + oo);
+        v[0] = mk.x > 0.f ? v[0] : 0.f; v[1] = mk.y > 0.f ? v[1] : 0.f;
+        v[2] = mk.z > 0.f ? v[2] : 0.f; v[3] = mk.w > 0.f ? v[3] : 0.f;
+      }
+      *reinterpret_cast<float4*>(y + oo) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -329,7 +445,10 @@ int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const floa
   wino_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
   UMPR_LAUNCH_CHECK("wino_weights");
   const long TT = (T + WBN - 1) / WBN;
-  wino_input_kernel<<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
+  if ((W / 2) % 2 == 0)
+    wino_input_pair_kernel<<<nblk((long)S * WK * TT * WBN / 2, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
+  else
+    wino_input_kernel<<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
   UMPR_LAUNCH_CHECK("wino_input");
   WinoGemmParams p{U, V, Mx, MT, S, C, Tpad, TT, MT * WBM};
   const long groups = (16 * TT + 7) / 8 * 8;
@@ -338,7 +457,10 @@ int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const floa
     wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_gemm");
-  wino_output_kernel<<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
+  if ((W / 2) % 2 == 0)
+    wino_output_pair_kernel<<<nblk((long)M * T / 2, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
+  else
+    wino_output_kernel<<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
   UMPR_LAUNCH_CHECK("wino_output");
   return 0;
 }
