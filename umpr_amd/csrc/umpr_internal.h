@@ -51,6 +51,9 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
                      hipStream_t s);
 // winograd.hip
 size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W);
+size_t umpr_wino_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W);
+int umpr_wino_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
+                    int accumulate, float* ws, size_t ws_floats, hipStream_t s);
 int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
                       int N, int Cin, int Cout, int H, int W, int relu, float* ws, size_t ws_floats, hipStream_t s);
 int umpr_conv3x3_flip_transpose(const float* w, float* wt, int Cout, int Cin, hipStream_t s);
@@ -126,7 +129,8 @@ int umpr_gate_bwd_impl(const float* sa, const float* w, const float* view_p, con
 enum UmprKernelFamily { UMPR_K_CONV_IGEMM = 0, UMPR_K_CONV_WGRAD = 1, UMPR_K_GEMM = 2, UMPR_K_GRU = 3,
                         UMPR_K_WINO_GEMM = 4 /* nested inside CONV_IGEMM: executed MFMA FLOPs of the Winograd GEMM */,
                         UMPR_K_CONV_DGRAD = 5 /* the conv kernels of family 0 run as data gradient */,
-                        UMPR_K_COUNT = 6 };
+                        UMPR_K_WINO_WGRAD_GEMM = 6 /* nested inside CONV_WGRAD: executed FLOPs of the Winograd wgrad GEMM */,
+                        UMPR_K_COUNT = 7 };
 struct UmprProfScope {
   UmprProfScope(int family, double work, hipStream_t s);
   ~UmprProfScope();

@@ -464,3 +464,302 @@ int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const floa
   UMPR_LAUNCH_CHECK("wino_output");
   return 0;
 }
+
+// =====================================================================================================================
+// Winograd weight gradient, F(3x3, 2x2):   dW = G^T [ sum_t (A g_t A^T) .* (B^T d_t B) ] G
+//   g_t = 2x2 tile of the output gradient, d_t = the 4x4 input tile of the forward transform (same B), t over all
+//   tiles of the batch.  16 GEMMs  P[xi][m][c] = sum_t Gy[xi][m][t] * V[xi][c][t]  with the reduction over tiles:
+//   both operands are t-contiguous ("NT"), the tile range is split over workgroups (split-K) and the partial
+//   products are summed in a fixed order by the finish kernel, which also applies G^T . G (4x4 -> 3x3).
+//   A = [1 0; 1 1; 1 -1; 0 -1],  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1].
+// =====================================================================================================================
+namespace {
+
+// Gy[xi][m][t] = (A g A^T)[xi],  g = dy[n][m][2ty..2ty+1][2tx..2tx+1];  columns t in [T, Tw) are written as zeros
+__global__ void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ Gy, int N, int Mch, int H, int W,
+                               long Tpad, long Tw, int Mpad) {
+  const int TH = H / 2, TW = W / 2;
+  const long T = (long)N * TH * TW;
+  const long total = (long)Mch * Tw;
+  const long per = (long)Mpad * Tpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i % Tw;
+    const int m = (int)(i / Tw);
+    float* dst = Gy + (long)m * Tpad + t;
+    if (t >= T) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) dst[(long)a * per] = 0.f;
+      continue;
+    }
+    const int tx = (int)(t % TW);
+    const long r = t / TW;
+    const int ty = (int)(r % TH), n = (int)(r / TH);
+    const float* src = dy + (((long)n * Mch + m) * H + 2 * ty) * W + 2 * tx;
+    const float2 g0 = *reinterpret_cast<const float2*>(src);
+    const float2 g1 = *reinterpret_cast<const float2*>(src + W);
+    // A g (4x2): rows g0, g0+g1, g0-g1, -g1;  then (A g) A^T per row: p, p+q, p-q, -q
+    const float rp[4] = {g0.x, g0.x + g1.x, g0.x - g1.x, -g1.x};
+    const float rq[4] = {g0.y, g0.y + g1.y, g0.y - g1.y, -g1.y};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      dst[(long)(a * 4 + 0) * per] = rp[a];
+      dst[(long)(a * 4 + 1) * per] = rp[a] + rq[a];
+      dst[(long)(a * 4 + 2) * per] = rp[a] - rq[a];
+      dst[(long)(a * 4 + 3) * per] = -rq[a];
+    }
+  }
+}
+
+// db[m] = sum over n, y, x of dy[n][m][y][x]: one workgroup per channel, fixed order
+__global__ void wino_bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int N, int Mch, long HW,
+                                      int accumulate) {
+  __shared__ float part[256];
+  const int m = blockIdx.x;
+  float a = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float* src = dy + ((long)n * Mch + m) * HW;
+    float b = 0.f;
+    for (long i = threadIdx.x; i < HW; i += 256) b += src[i];
+    a += b;
+  }
+  part[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[m] = accumulate ? db[m] + part[0] : part[0];
+}
+
+struct WinoWgradParams {
+  const float* Gy;   // [16][Mpad][Tpad]
+  const float* V;    // [16][Cpad][Tpad]
+  float* P;          // [splits][16][Mpad][Cpad]
+  int MT, CT, Mpad, Cpad;
+  long Tpad;
+  int stages;            // Tpad / 32
+  int stages_per_split;
+};
+
+constexpr int WLDT = 130;   // LDS row pitch of the transposed ([k][row]) operand images
+
+// grid.x = 16 * MT * CT * splits.  Both operands arrive k-contiguous ([row][t]); each thread loads float4 along t and
+// scatters the four values into the [k][row] image the MFMA fragment reads expect (scalar LDS stores, 2-way at most).
+__global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams p) {
+  constexpr int LD = WLDT;
+  constexpr int TM = 2, TN = 2;
+  constexpr int KS = WK / 2;
+  constexpr int NV = 4;
+  constexpr int SFLUSH = 4;
+  __shared__ __attribute__((aligned(16))) float As[2][WK * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WK * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  long b = blockIdx.x;
+  const int ct = (int)(b % p.CT); b /= p.CT;
+  const int mt = (int)(b % p.MT); b /= p.MT;
+  const int xi = (int)(b % 16);
+  const int split = (int)(b / 16);
+  const int s_begin = split * p.stages_per_split;
+  const int s_end = min(p.stages, s_begin + p.stages_per_split);
+  const int ns = s_end - s_begin;   // >= 1 by construction
+
+  // unit u = tid + 256 v: row = u / 8 (0..127), k-quad = u % 8: eight lanes cover one row's 128 contiguous bytes
+  const int urow = tid >> 3, uq = tid & 7;
+  const float* pa = p.Gy + ((long)xi * p.Mpad + mt * WBM + urow) * p.Tpad + (long)s_begin * WK + 4 * uq;
+  const float* pb = p.V + ((long)xi * p.Cpad + ct * WBN + urow) * p.Tpad + (long)s_begin * WK + 4 * uq;
+  const long rstep = 32 * p.Tpad;   // 32 rows per v
+  float* sa = &As[0][(4 * uq) * LD + urow];
+  float* sb = &Bs[0][(4 * uq) * LD + urow];
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  auto lda = [&](int v, int s) { return *reinterpret_cast<const float4*>(pa + (long)s * WK + v * rstep); };
+  auto ldb = [&](int v, int s) { return *reinterpret_cast<const float4*>(pb + (long)s * WK + v * rstep); };
+  auto sta = [&](int v, int buf, const float4& r) {
+    float* d = sa + buf * (WK * LD) + 32 * v;
+    d[0] = r.x; d[LD] = r.y; d[2 * LD] = r.z; d[3 * LD] = r.w;
+  };
+  auto stb = [&](int v, int buf, const float4& r) {
+    float* d = sb + buf * (WK * LD) + 32 * v;
+    d[0] = r.x; d[LD] = r.y; d[2 * LD] = r.z; d[3 * LD] = r.w;
+  };
+  auto piece = [&](int q, int sn, int nbuf) {
+    switch (q) {
+      case 0: ra0 = lda(0, sn); break;
+      case 1: ra1 = lda(1, sn); break;
+      case 2: ra2 = lda(2, sn); break;
+      case 3: ra3 = lda(3, sn); break;
+      case 4: rb0 = ldb(0, sn); break;
+      case 5: rb1 = ldb(1, sn); break;
+      case 6: rb2 = ldb(2, sn); break;
+      case 7: rb3 = ldb(3, sn); break;
+      case 8: sta(0, nbuf, ra0); break;
+      case 9: sta(1, nbuf, ra1); break;
+      case 10: sta(2, nbuf, ra2); break;
+      case 11: sta(3, nbuf, ra3); break;
+      case 12: stb(0, nbuf, rb0); break;
+      case 13: stb(1, nbuf, rb1); break;
+      case 14: stb(2, nbuf, rb2); break;
+      default: stb(3, nbuf, rb3); break;
+    }
+  };
+
+  f32x16 acc[TM][TN], tot[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+#pragma unroll
+  for (int q = 0; q < 16; ++q) piece(q, 0, 0);
+  __syncthreads();
+  for (int s0 = 0; s0 < ns; s0 += SFLUSH) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int s1 = min(ns, s0 + SFLUSH);
+    for (int s = s0; s < s1; ++s) {
+      const int cur = s & 1;
+      const int sn = min(s + 1, ns - 1);
+      const float* as = As[cur] + half * LD + wm * 64 + l31;
+      const float* bs = Bs[cur] + half * LD + wn * 64 + l31;
+      float a[2][TM], bq[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bq[0][j] = bs[j * 32];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const int cb = kk & 1, nb = cb ^ 1;
+        const int k1 = kk + 1;
+#pragma unroll
+        for (int m = 0; m < TM * TN; ++m) {
+          const int i = m / TN, j = m % TN;
+          acc[i][j] = mfma32(a[cb][i], bq[cb][j], acc[i][j]);
+          if (m == 0 && k1 < KS) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) a[nb][ii] = as[2 * k1 * LD + ii * 32];
+          }
+          if (m == 1 && k1 < KS) {
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) bq[nb][jj] = bs[2 * k1 * LD + jj * 32];
+          }
+          if (m == 3) piece(kk, sn, cur ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
+  }
+  float* Pb = p.P + ((((long)split * 16 + xi) * p.Mpad + mt * WBM) * p.Cpad) + ct * WBN;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Pb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Cpad + wn * 64 + j * 32 + l31] = tot[i][j][r];
+}
+
+// dw[m][c][3][3] (+)= G^T (sum_split P[split][.][m][c]) G
+__global__ void wino_wgrad_finish_kernel(const float* __restrict__ P, int splits, int Mch, int C, int Mpad, int Cpad,
+                                         float* __restrict__ dw, int accumulate) {
+  const long total = (long)Mch * C;
+  const long per = (long)Mpad * Cpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int m = (int)(i / C);
+    float v[4][4];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+      float acc = 0.f;
+      for (int sp = 0; sp < splits; ++sp) acc += P[((long)sp * 16 + a) * per + (long)m * Cpad + c];
+      v[a >> 2][a & 3] = acc;
+    }
+    float gv[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      gv[0][b] = v[0][b] + 0.5f * (v[1][b] + v[2][b]);
+      gv[1][b] = 0.5f * (v[1][b] - v[2][b]);
+      gv[2][b] = 0.5f * (v[1][b] + v[2][b]) + v[3][b];
+    }
+    float* d = dw + i * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float o0 = gv[a][0] + 0.5f * (gv[a][1] + gv[a][2]);
+      const float o1 = 0.5f * (gv[a][1] - gv[a][2]);
+      const float o2 = 0.5f * (gv[a][1] + gv[a][2]) + gv[a][3];
+      if (accumulate) { d[a * 3 + 0] += o0; d[a * 3 + 1] += o1; d[a * 3 + 2] += o2; }
+      else { d[a * 3 + 0] = o0; d[a * 3 + 1] = o1; d[a * 3 + 2] = o2; }
+    }
+  }
+}
+
+constexpr int kWinoWgradTargetWgs = 1024;
+
+struct WinoWgradGeom { long T, Tpad; int MT, CT, Mpad, Cpad, stages, splits, stages_per_split; };
+WinoWgradGeom wino_wgrad_geom(int N, int Cin, int Cout, int H, int W) {
+  WinoWgradGeom g;
+  g.T = (long)N * (H / 2) * (W / 2);
+  g.Tpad = wino_tpad(g.T);
+  g.MT = (Cout + WBM - 1) / WBM; g.CT = (Cin + WBN - 1) / WBN;
+  g.Mpad = g.MT * WBM; g.Cpad = g.CT * WBN;
+  g.stages = (int)(g.Tpad / WK);
+  const int tiles = 16 * g.MT * g.CT;
+  int splits = (kWinoWgradTargetWgs + tiles - 1) / tiles;
+  const int max_splits = g.stages / 8 > 0 ? g.stages / 8 : 1;   // at least 8 stages (256 tiles) per workgroup
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  g.stages_per_split = (g.stages + splits - 1) / splits;
+  g.splits = (g.stages + g.stages_per_split - 1) / g.stages_per_split;
+  return g;
+}
+
+}  // namespace
+
+// workspace: Gy [16][Mpad][Tpad] + V [16][Cpad][Tpad] + P [splits][16][Mpad][Cpad]  (floats)
+size_t umpr_wino_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W) {
+  const WinoWgradGeom g = wino_wgrad_geom(N, Cin, Cout, H, W);
+  return (size_t)16 * ((size_t)g.Mpad * g.Tpad + (size_t)g.Cpad * g.Tpad + (size_t)g.splits * g.Mpad * g.Cpad) + 64;
+}
+
+int umpr_wino_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
+                    int accumulate, float* ws, size_t ws_floats, hipStream_t s) {
+  UMPR_REQUIRE((H % 2) == 0 && (W % 2) == 0, "winograd wgrad: odd map %dx%d", H, W);
+  UMPR_REQUIRE(ws_floats >= umpr_wino_wgrad_ws_floats(N, Cin, Cout, H, W), "winograd wgrad: workspace too small");
+  const WinoWgradGeom g = wino_wgrad_geom(N, Cin, Cout, H, W);
+  float* Gy = ws;
+  float* V = Gy + (size_t)16 * g.Mpad * g.Tpad;
+  float* P = V + (size_t)16 * g.Cpad * g.Tpad;
+  // rows m >= Cout of Gy are never written: they only feed rows of P that the finish kernel does not read, but they
+  // must be finite?  No: every P element is a dot product of ONE Gy row with ONE V row, so garbage stays in its row.
+  wino_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
+  UMPR_LAUNCH_CHECK("wino_dy");
+  if ((W / 2) % 2 == 0)
+    wino_input_pair_kernel<<<nblk((long)g.Cpad * g.Tpad / 2, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
+  else
+    wino_input_kernel<<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
+  UMPR_LAUNCH_CHECK("wino_input(wgrad)");
+  WinoWgradParams p{Gy, V, P, g.MT, g.CT, g.Mpad, g.Cpad, g.Tpad, g.stages, g.stages_per_split};
+  {
+    UmprProfScope prof(UMPR_K_WINO_WGRAD_GEMM, 2.0 * 16 * (double)Cout * Cin * g.T, s);
+    wino_wgrad_gemm_kernel<<<(unsigned)(16 * g.MT * g.CT * g.splits), 256, 0, s>>>(p);
+  }
+  UMPR_LAUNCH_CHECK("wino_wgrad_gemm");
+  wino_wgrad_finish_kernel<<<nblk((long)Cout * Cin, 4096), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad, dw, accumulate);
+  UMPR_LAUNCH_CHECK("wino_wgrad_finish");
+  if (db) {
+    wino_bias_grad_kernel<<<Cout, 256, 0, s>>>(dy, db, N, Cout, (long)H * W, accumulate);
+    UMPR_LAUNCH_CHECK("wino_bias_grad");
+  }
+  return 0;
+}
