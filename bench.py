@@ -179,7 +179,8 @@ def main():
         dt = float(t.item())
 
     fam = {}
-    for name, idx in (("conv3x3_fwd", 0), ("conv3x3_dgrad", 5), ("conv3x3_wgrad", 1), ("gemm_f32", 2), ("wino_gemm", 4)):
+    for name, idx in (("conv3x3_fwd", 0), ("conv3x3_dgrad", 5), ("conv3x3_wgrad", 1), ("gemm_f32", 2), ("wino_gemm", 4),
+                      ("wino_wgrad_gemm", 6)):
         ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
         L.fn["umpr_profile_read"](idx, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
         fam[name] = (ms.value, work.value, n.value)

@@ -200,7 +200,8 @@ int umpr_debug_poison_lds(void* sink, void* stream);
  * family with HIP events on the launch stream.  family: 0 conv3x3 forward (direct implicit GEMM / Winograd),
  * 1 conv3x3 wgrad, 2 generic GEMM, 3 GRU, 4 the Winograd batched GEMM alone (nested inside families 0 and 5; its
  * work is the MFMA FLOPs executed, 1/2.25 of the direct-convolution FLOPs counted for the same launch), 5 the
- * family-0 kernels run as data gradient (these overlap with wgrad on the library's side stream).  read() synchronises the recorded events and returns totals since reset():
+ * family-0 kernels run as data gradient (these overlap with wgrad on the library's side stream), 6 the Winograd
+ * weight-gradient GEMM alone (nested inside family 1, executed FLOPs).  read() synchronises the recorded events and returns totals since reset():
  * milliseconds, algorithmic FLOPs, launches. */
 int umpr_profile_enable(int on);
 int umpr_profile_reset(void);

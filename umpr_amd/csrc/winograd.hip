@@ -510,25 +510,64 @@ __global__ void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__
   }
 }
 
-// db[m] = sum over n, y, x of dy[n][m][y][x]: one workgroup per channel, fixed order
-__global__ void wino_bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int N, int Mch, long HW,
-                                      int accumulate) {
-  __shared__ float part[256];
-  const int m = blockIdx.x;
-  float a = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const float* src = dy + ((long)n * Mch + m) * HW;
-    float b = 0.f;
-    for (long i = threadIdx.x; i < HW; i += 256) b += src[i];
-    a += b;
+// two horizontally adjacent tiles per thread (even tile rows): float4 loads of dy, float2 stores
+__global__ void wino_dy_pair_kernel(const float* __restrict__ dy, float* __restrict__ Gy, int N, int Mch, int H, int W,
+                                    long Tpad, long Tw, int Mpad) {
+  const int TH = H / 2, TW = W / 2;
+  const long T = (long)N * TH * TW;
+  const long Tw2 = Tw / 2;
+  const long total = (long)Mch * Tw2;
+  const long per = (long)Mpad * Tpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = 2 * (i % Tw2);
+    const int m = (int)(i / Tw2);
+    float* dst = Gy + (long)m * Tpad + t;
+    if (t >= T) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) *reinterpret_cast<float2*>(dst + (long)a * per) = make_float2(0.f, 0.f);
+      continue;
+    }
+    const int tx = (int)(t % TW);
+    const long r = t / TW;
+    const int ty = (int)(r % TH), n = (int)(r / TH);
+    const float* src = dy + (((long)n * Mch + m) * H + 2 * ty) * W + 2 * tx;
+    const float4 g0 = *reinterpret_cast<const float4*>(src);        // row 0: tile 0 (x, y), tile 1 (z, w)
+    const float4 g1 = *reinterpret_cast<const float4*>(src + W);    // row 1
+    const float2 rp[4] = {make_float2(g0.x, g0.z), make_float2(g0.x + g1.x, g0.z + g1.z),
+                          make_float2(g0.x - g1.x, g0.z - g1.z), make_float2(-g1.x, -g1.z)};
+    const float2 rq[4] = {make_float2(g0.y, g0.w), make_float2(g0.y + g1.y, g0.w + g1.w),
+                          make_float2(g0.y - g1.y, g0.w - g1.w), make_float2(-g1.y, -g1.w)};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      *reinterpret_cast<float2*>(dst + (long)(a * 4 + 0) * per) = rp[a];
+      *reinterpret_cast<float2*>(dst + (long)(a * 4 + 1) * per) = make_float2(rp[a].x + rq[a].x, rp[a].y + rq[a].y);
+      *reinterpret_cast<float2*>(dst + (long)(a * 4 + 2) * per) = make_float2(rp[a].x - rq[a].x, rp[a].y - rq[a].y);
+      *reinterpret_cast<float2*>(dst + (long)(a * 4 + 3) * per) = make_float2(-rq[a].x, -rq[a].y);
+    }
   }
-  part[threadIdx.x] = a;
+}
+
+// db[m] = sum over n, y, x of dy[n][m][y][x], two fixed-order stages: one workgroup per (n, m) plane, then over n
+__global__ void wino_bias_part_kernel(const float* __restrict__ dy, float* __restrict__ part, long HW) {
+  __shared__ float red[256];
+  const float4* src = reinterpret_cast<const float4*>(dy + (long)blockIdx.x * HW);   // plane index = n * Mch + m
+  float a = 0.f;
+  for (long i = threadIdx.x; i < HW / 4; i += 256) { const float4 v = src[i]; a += (v.x + v.y) + (v.z + v.w); }
+  red[threadIdx.x] = a;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) db[m] = accumulate ? db[m] + part[0] : part[0];
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void wino_bias_sum_kernel(const float* __restrict__ part, float* __restrict__ db, int N, int Mch,
+                                     int accumulate) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Mch) return;
+  float a = 0.f;
+  for (int n = 0; n < N; ++n) a += part[(long)n * Mch + m];
+  db[m] = accumulate ? db[m] + a : a;
 }
 
 struct WinoWgradParams {
@@ -742,7 +781,10 @@ int umpr_wino_wgrad(const float* dy, const float* x, float* dw, float* db, int N
   float* P = V + (size_t)16 * g.Cpad * g.Tpad;
   // rows m >= Cout of Gy are never written: they only feed rows of P that the finish kernel does not read, but they
   // must be finite?  No: every P element is a dot product of ONE Gy row with ONE V row, so garbage stays in its row.
-  wino_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
+  if ((W / 2) % 2 == 0)
+    wino_dy_pair_kernel<<<nblk((long)Cout * g.Tpad / 2, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
+  else
+    wino_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   UMPR_LAUNCH_CHECK("wino_dy");
   if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)g.Cpad * g.Tpad / 2, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
@@ -757,9 +799,13 @@ int umpr_wino_wgrad(const float* dy, const float* x, float* dw, float* db, int N
   UMPR_LAUNCH_CHECK("wino_wgrad_gemm");
   wino_wgrad_finish_kernel<<<nblk((long)Cout * Cin, 4096), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad, dw, accumulate);
   UMPR_LAUNCH_CHECK("wino_wgrad_finish");
-  if (db) {
-    wino_bias_grad_kernel<<<Cout, 256, 0, s>>>(dy, db, N, Cout, (long)H * W, accumulate);
-    UMPR_LAUNCH_CHECK("wino_bias_grad");
+  if (db) {  // P is free again after the finish kernel (same stream): N * Cout partial sums fit in it
+    UMPR_REQUIRE((size_t)N * Cout <= (size_t)g.splits * 16 * g.Mpad * g.Cpad && ((long)H * W) % 4 == 0,
+                 "winograd wgrad: bias-gradient scratch");
+    wino_bias_part_kernel<<<(unsigned)((long)N * Cout), 256, 0, s>>>(dy, P, (long)H * W);
+    UMPR_LAUNCH_CHECK("wino_bias_part");
+    wino_bias_sum_kernel<<<(Cout + 255) / 256, 256, 0, s>>>(P, db, N, Cout, accumulate);
+    UMPR_LAUNCH_CHECK("wino_bias_sum");
   }
   return 0;
 }
