@@ -173,3 +173,37 @@ def test_training_is_bitwise_reproducible(dev, review_net_only):
     assert runs[0][0] == runs[1][0]
     for k in runs[0][1]:
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
+def test_in_place_gradients_keep_accumulation_semantics(dev):
+    """VGG gradients are written straight into the optimiser's arena on the first backward after zero_grad(); a second
+    backward without zero_grad must ADD (torch semantics), and a parameter no backward touched must read as zero."""
+    from umpr_amd.model import UMPR
+    from umpr_amd.optim import FusedAdam
+    from umpr_amd.synthetic import make_batch, make_param_state
+    P = make_param_state(141, 50, 400, 1, False, m_scale=0.05)
+    model = UMPR(_cfg(views=["unknown"]), P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    model = model.to(dev).eval()          # eval: no dropout, two passes are identical
+    opt = FusedAdam(model, 1e-3, 1e-3)
+    batch = make_batch(142, 2, 400, 1)
+    names = ["visual_net.vgg16.0.features.0.weight", "visual_net.vgg16.0.features.28.bias",
+             "visual_net.vgg16.0.classifier.0.weight", "visual_net.vgg16.0.classifier.6.bias", "review_net.r_net.M"]
+    params = dict(model.named_parameters())
+    opt.zero_grad()
+    assert params[names[0]]._umpr_fresh
+    model(*batch)[1].backward()
+    assert not params[names[0]]._umpr_fresh
+    once = {k: params[k].grad.clone() for k in names}
+    model(*batch)[1].backward()           # no zero_grad in between
+    for k in names:
+        assert torch.allclose(params[k].grad, 2 * once[k], rtol=1e-5, atol=1e-7 * float(once[k].abs().max())), k
+    opt.zero_grad()
+    for g in opt.groups:                  # stale contents in the in-place slices, nothing writes them before step()
+        for p in g.direct:
+            p.grad.fill_(3.0)
+    before = params[names[2]].detach().clone()
+    opt.step()
+    assert float(params[names[2]].grad.abs().max()) == 0.0
+    # zero gradient: the first Adam step moves a weight by at most lr * (wd * |w|-driven update) <= lr
+    assert float((params[names[2]].detach() - before).abs().max()) <= 1.001e-3

@@ -198,3 +198,24 @@ def test_checkpoint_roundtrip(tmp_path):
     g = o2.groups[0]
     off, k = g.offsets[g.names[0]]
     assert g.params[0].data_ptr() == g.p[off:off + k].data_ptr()
+
+
+def test_zero_grad_skips_in_place_gradients():
+    """Parameters flagged `_umpr_direct` (their backward node writes p.grad in place) are not zero-filled: zero_grad marks
+    them fresh instead; all other arena ranges are zeroed.  Host logic only - no kernel runs."""
+    from umpr_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    model = _Tiny()
+    for p in model.classifier.parameters():
+        p._umpr_direct = True
+    opt = FusedAdam(model, 1e-3, 1e-3)
+    for g in opt.groups:
+        g.g.fill_(7.0)
+    opt.zero_grad()
+    for name, p in model.named_parameters():
+        if name.startswith("classifier."):
+            assert p._umpr_fresh and float(p.grad.min()) == 7.0, name      # untouched, to be overwritten by backward
+        else:
+            assert not getattr(p, "_umpr_fresh", False) and float(p.grad.abs().max()) == 0.0, name
+    covered = sum(hi - lo for g in opt.groups for lo, hi in g.zero_ranges) + sum(p.numel() for g in opt.groups for p in g.direct)
+    assert covered == sum(g.numel for g in opt.groups)

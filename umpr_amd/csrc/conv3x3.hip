@@ -995,6 +995,11 @@ static int g_conv_bn = 0;  // UMPR_CONV_BN: 0 auto (128x128 bulk + 128x64 tail),
 static bool g_conv_force_v1 = false;  // UMPR_CONV_V1=1 selects the generic gather kernel (A/B runs)
 static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; const char* q = getenv("UMPR_CONV_BN"); g_conv_bn = q ? atoi(q) : 0; const char* wq = getenv("UMPR_CONV_WINO"); g_conv_no_wino = wq && wq[0] == '0'; } } g_conv_env_init;
 static bool wino_layer(int H, int W) { return H == W && (W == 56 || W == 28 || W == 14); }
+// 112x112 maps with >= 128 channels on both sides (conv2_2): Winograd only in backward (UMPR_WINO_112=1, experiment)
+static const bool g_wino_112 = [] { const char* v = getenv("UMPR_WINO_112"); return v && v[0] == '1'; }();
+static bool wino_bwd_layer(int C, int M, int H, int W) {
+  return wino_layer(H, W) || (g_wino_112 && H == W && W == 112 && C >= 128 && M >= 128);
+}
 
 // scratch floats a conv call needs: the packed weights, or (deep layers) the Winograd U / V / M buffers
 size_t umpr_conv3x3_pack_floats(int N, int Cin, int Cout, int H, int W) {
@@ -1003,7 +1008,7 @@ size_t umpr_conv3x3_pack_floats(int N, int Cin, int Cout, int H, int W) {
   const size_t c = (size_t)Cin * Cout * 9;                               // plain flip-transpose (generic kernel)
   size_t m = a > b ? a : b;
   if (c > m) m = c;
-  if (wino_layer(H, W) && !g_conv_no_wino) {
+  if (wino_bwd_layer(Cin, Cout, H, W) && !g_conv_no_wino) {
     const size_t f = umpr_wino_ws_floats(N, Cin, Cout, H, W), t = umpr_wino_ws_floats(N, Cout, Cin, H, W);
     if (f > m) m = f;
     if (t > m) m = t;
@@ -1021,7 +1026,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
   const int M = transposed ? Cin : Cout;   // output channels of this launch
   const int C = transposed ? Cout : Cin;   // reduction channels
   const long NP = (long)N * H * W;
-  if (wino_layer(H, W) && !g_conv_no_wino && !g_conv_force_v1 && wpack && C >= 32 &&
+  if ((transposed ? wino_bwd_layer(C, M, H, W) : wino_layer(H, W)) && !g_conv_no_wino && !g_conv_force_v1 && wpack && C >= 32 &&
       wpack_floats >= umpr_wino_ws_floats(N, C, M, H, W)) {
     // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs; timed under the same family with the direct conv's FLOP count
     UmprProfScope prof(transposed ? UMPR_K_CONV_DGRAD : UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
@@ -1088,7 +1093,7 @@ static void wgrad_geometry(int W, int* R, int* CW) {
 
 static const bool g_wgrad_wino = [] { const char* v = getenv("UMPR_WGRAD_WINO"); return !(v && v[0] == '0'); }();
 static bool wgrad_wino_layer(int Cin, int Cout, int H, int W) {
-  return g_wgrad_wino && !g_conv_force_v1 && wino_layer(H, W) && Cin >= 32 && Cout >= 32;
+  return g_wgrad_wino && !g_conv_force_v1 && wino_bwd_layer(Cin, Cout, H, W) && Cin >= 32 && Cout >= 32;
 }
 
 size_t umpr_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {

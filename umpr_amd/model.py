@@ -215,6 +215,27 @@ class _Control(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------- K10
+def _grad_targets(params):
+    """Where a backward node writes each parameter gradient: straight into ``p.grad`` (a view of FusedAdam's flat
+    arena) when the optimiser marked it fresh in ``zero_grad()`` - no zero fill, no temporary, no accumulate kernel -
+    else into a new tensor that autograd accumulates as usual (second backward without zero_grad, plain optimisers)."""
+    dst, direct = [], []
+    for p in params:
+        g = p.grad
+        ok = (g is not None and getattr(p, "_umpr_fresh", False) and g.is_contiguous() and g.shape == p.shape
+              and g.device == p.device and g.dtype == torch.float32)
+        dst.append(g if ok else torch.empty_like(p))
+        direct.append(ok)
+    return dst, direct
+
+
+def _grad_returns(params, dst, direct):
+    for p, d in zip(params, direct):
+        if d:
+            p._umpr_fresh = False
+    return [None if d else g for g, d in zip(dst, direct)]
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return arr, ctypes.cast(arr, ctypes.c_void_p)
@@ -230,6 +251,7 @@ class _VGGFeatures(torch.autograd.Function):
         assert tuple(images.shape[1:]) == (3, 224, 224), "VGG16 kernels take 3x224x224 images (src/dataset.py:146)"
         dev = images.device
         images = _c(images)
+        params_in = params
         params = [_c(p) for p in params]
         acts = torch.empty(lib().size("umpr_vgg16_act_bytes", n) // 4, device=dev, dtype=torch.float32)
         ws, wsb = _ws(lib().size("umpr_vgg16_fwd_ws_bytes", n), dev)
@@ -239,6 +261,7 @@ class _VGGFeatures(torch.autograd.Function):
         off = lib().size("umpr_vgg16_pool5_offset", n) // 4
         pool5 = acts[off:off + n * 25088].view(n, 25088)
         ctx.save_for_backward(images, acts, *params)
+        ctx.param_objs = params_in
         ctx.mark_non_differentiable(acts)
         return pool5, acts
 
@@ -247,21 +270,23 @@ class _VGGFeatures(torch.autograd.Function):
         images, acts, *params = ctx.saved_tensors
         n = images.shape[0]
         dev = images.device
-        grads = [torch.empty_like(p) for p in params]
+        grads, direct = _grad_targets(ctx.param_objs)
         ws, wsb = _ws(lib().size("umpr_vgg16_features_bwd_ws_bytes", n), dev)
         keep_p, parr = _ptr_array(params + params[:6])
         keep_g, garr = _ptr_array(grads + grads[:6])
         lib().call("umpr_vgg16_features_bwd", images, parr, n, acts, _c(d_pool5), garr, ws, wsb, stream_ptr())
-        return (None, *grads)
+        return (None, *_grad_returns(ctx.param_objs, grads, direct))
 
 
 class _VGGClassifier(torch.autograd.Function):
     """Linear(25088,4096)-ReLU-Dropout-Linear(4096,4096)-ReLU-Dropout-Linear(4096,1000) on the pooled features."""
 
     @staticmethod
-    def forward(ctx, pool5, acts, train, masks_in, seed, *params):
+    def forward(ctx, pool5, acts, train, masks_in, seed, owner, *params):
         n = pool5.shape[0]
         dev = pool5.device
+        ctx.param_objs = params
+        ctx.owner = owner
         params = [_c(p) for p in params]
         use_masks = masks_in is not None
         masks = _c(masks_in) if use_masks else torch.empty(2, n, 4096, device=dev, dtype=torch.uint8)
@@ -279,14 +304,18 @@ class _VGGClassifier(torch.autograd.Function):
         acts, masks, *params = ctx.saved_tensors
         n = d_out.shape[0]
         dev = d_out.device
-        grads = [torch.empty_like(p) for p in params]
+        grads, direct = _grad_targets(ctx.param_objs)
         d_pool5 = torch.empty(n, 25088, device=dev, dtype=torch.float32)
         ws, wsb = _ws(lib().size("umpr_vgg16_classifier_bwd_ws_bytes", n), dev)
         keep_p, parr = _ptr_array([params[0]] * 26 + params)
         keep_g, garr = _ptr_array([grads[0]] * 26 + grads)
         lib().call("umpr_vgg16_classifier_bwd", parr, n, int(ctx.dropout), acts, masks, _c(d_out), garr, d_pool5, ws,
                    wsb, stream_ptr())
-        return (d_pool5, None, None, None, None, *grads)
+        out = _grad_returns(ctx.param_objs, grads, direct)
+        if all(direct) and ctx.owner is not None:   # written in place: no AccumulateGrad hook will announce them
+            for cb in ctx.owner.grad_callbacks:
+                cb()
+        return (d_pool5, None, None, None, None, None, *out)
 
 
 # --------------------------------------------------------------------------------------------- K11-K12
@@ -438,6 +467,9 @@ class VGG16(nn.Module):
                 nn.init.constant_(m.bias, 0)
         self.dropout_masks = None  # optional injected keep-masks uint8 [2][n][4096] (parity tests)
         self._calls = 0
+        self.grad_callbacks = []   # called once the classifier gradients have been written in place (GradReducer)
+        for p in self.parameters():
+            p._umpr_direct = True  # one backward node writes each of these exactly once per step
 
     def param_list(self):
         ps = []
@@ -454,7 +486,7 @@ class VGG16(nn.Module):
         seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
         ps = self.param_list()
         pool5, acts = _VGGFeatures.apply(images, *ps[:26])
-        return _VGGClassifier.apply(pool5, acts, self.training, self.dropout_masks, seed, *ps[26:])
+        return _VGGClassifier.apply(pool5, acts, self.training, self.dropout_masks, seed, self, *ps[26:])
 
 
 class VisualNet(nn.Module):

@@ -38,6 +38,18 @@ class _Group:
                 p.grad = self.g[off:off + k].view(p.shape)
                 self.offsets[name] = (off, k)
                 off += k
+        # parameters whose backward node writes the gradient in place (model.py::_grad_targets): their arena slices need
+        # no zero fill; everything else is zeroed as merged ranges
+        self.direct = [p for p in self.params if getattr(p, "_umpr_direct", False)]
+        self.zero_ranges = []
+        for name, p in zip(self.names, self.params):
+            if getattr(p, "_umpr_direct", False):
+                continue
+            lo, k = self.offsets[name]
+            if self.zero_ranges and self.zero_ranges[-1][1] == lo:
+                self.zero_ranges[-1][1] = lo + k
+            else:
+                self.zero_ranges.append([lo, lo + k])
 
 
 class FusedAdam:
@@ -53,6 +65,7 @@ class FusedAdam:
         device = named[0][1].device
         self.groups = [_Group([(n, p) for n, p in named if 'bias' not in n], l2_regularization, device),
                        _Group([(n, p) for n, p in named if 'bias' in n], 0.0, device)]
+        self.model = model
         self.base_lr = lr
         self.lr = lr
         self.lr_decay = lr_decay
@@ -62,13 +75,20 @@ class FusedAdam:
 
     def zero_grad(self):
         for g in self.groups:
-            g.g.zero_()
+            for lo, hi in g.zero_ranges:
+                g.g[lo:hi].zero_()
+            for p in g.direct:
+                p._umpr_fresh = True
 
     def step(self, grad_scale=1.0):
         if self.groups[0].p.device.type != "cuda":
             raise RuntimeError("FusedAdam.step launches a HIP kernel: the model must be on a cuda device")
         self.step_count += 1
         for g in self.groups:
+            for p in g.direct:
+                if getattr(p, "_umpr_fresh", False):   # no backward node wrote it since zero_grad: its gradient is zero
+                    p.grad.zero_()
+                    p._umpr_fresh = False
             if g.numel:
                 lib().call("umpr_adam_step", g.p, g.g, g.m, g.v, g.numel, self.lr, self.betas[0], self.betas[1],
                            self.eps, g.weight_decay, self.step_count, grad_scale, stream_ptr())

@@ -91,13 +91,23 @@ class GradReducer:
         if self.early is not None and active():
             self.pending = len(self.early[3])
             self.hooks = [p.register_post_accumulate_grad_hook(self._landed) for p in self.early[3]]
+            # gradients written in place (model.py::_grad_targets) pass no AccumulateGrad node: the module says so
+            for m in getattr(opt, "model", torch.nn.Module()).modules():
+                if hasattr(m, "grad_callbacks"):
+                    m.grad_callbacks.append(self._written_in_place)
 
     def _landed(self, _param=None):
         self.pending -= 1
         if self.pending == 0:
             self._fire()
 
+    def _written_in_place(self):
+        if self.early is not None and active() and not self.fired:
+            self._fire()
+
     def _fire(self):
+        if self.fired:
+            return
         arena, lo, hi, _ = self.early
         for chunk in torch.chunk(arena[lo:hi], self.n_buckets):
             self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
