@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--vocab", type=int, default=400003)
     ap.add_argument("--review_net_only", action="store_true")
     ap.add_argument("--realistic", action="store_true", help="ragged lengths instead of fully padded")
+    ap.add_argument("--eval", action="store_true", help="forward only (evaluate.py's path): inference samples/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -158,16 +159,23 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        if not args.eval:
+            return train_step(model, opt, batch, world, reducer)
+        with torch.no_grad():
+            model.eval()
+            return model(*batch)
+
     note("model and batch resident; warm-up")
     for _ in range(args.warmup):
-        train_step(model, opt, batch, world, reducer)
+        step()
     barrier()
     note("timed region")
     L.fn["umpr_profile_reset"]()
     L.fn["umpr_profile_enable"](1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, loss = train_step(model, opt, batch, world, reducer)
+        _, loss = step()
         loss_sum += loss.detach()
     barrier()
     dt = time.perf_counter() - t0
@@ -194,7 +202,7 @@ def main():
         executed = (work - 1.25 * 0.5 * fam["wino_gemm"][1]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic, traffic_note = pmc_traffic() if args.batch == 64 and not args.review_net_only else (None, "stored PMC pass is for batch 64")
         out = {
-            "metric": "training samples/sec", "value": value, "unit": "samples/s", "n_gpus": world,
+            "metric": "inference samples/sec" if args.eval else "training samples/sec", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
@@ -215,8 +223,8 @@ def main():
             "loss_mean": float(loss_sum.item()) / args.steps,
         }
         if not args.review_net_only:
-            out["model_tflops"] = value * GFLOP_PER_SAMPLE_TRAIN / 1e3 / world
-        if world == 1 and not args.no_cpu_baseline:
+            out["model_tflops"] = value * (GFLOP_PER_SAMPLE_TRAIN / 3.0 if args.eval else GFLOP_PER_SAMPLE_TRAIN) / 1e3 / world
+        if world == 1 and not args.no_cpu_baseline and not args.eval:
             out["cpu_baseline"] = cpu_baseline(args, P, rank)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()

@@ -122,6 +122,46 @@ class _Tiny(torch.nn.Module):
         return _JointClassifier.apply(self.features(x), c[0].weight, c[0].bias, c[2].weight, c[2].bias)
 
 
+class _JointClassifierInPlace(torch.autograd.Function):
+    """Same node, but following umpr_amd.model's in-place protocol: gradients of parameters the optimiser marked fresh
+    are written into p.grad directly, None is returned for them and the owner's grad_callbacks are called."""
+
+    @staticmethod
+    def forward(ctx, x, owner, w1, b1, w2, b2):
+        h = torch.tanh(x @ w1.t() + b1)
+        ctx.save_for_backward(x, w1, w2, h)
+        ctx.param_objs = (w1, b1, w2, b2)
+        ctx.owner = owner
+        return h @ w2.t() + b2
+
+    @staticmethod
+    def backward(ctx, dy):
+        from umpr_amd.model import _grad_returns, _grad_targets
+        x, w1, w2, h = ctx.saved_tensors
+        dh = (dy @ w2) * (1 - h * h)
+        vals = (dh.t() @ x, dh.sum(0), dy.t() @ h, dy.sum(0))
+        dst, direct = _grad_targets(ctx.param_objs)
+        for d, v in zip(dst, vals):
+            d.copy_(v)
+        out = _grad_returns(ctx.param_objs, dst, direct)
+        if all(direct):
+            for cb in ctx.owner.grad_callbacks:
+                cb()
+        return (dh @ w1, None, *out)
+
+
+class _TinyInPlace(_Tiny):
+    def __init__(self):
+        super().__init__()
+        self.grad_callbacks = []
+        for p in self.classifier.parameters():
+            p._umpr_direct = True
+
+    def forward(self, x):
+        c = self.classifier
+        return _JointClassifierInPlace.apply(self.features(x), self, c[0].weight, c[0].bias, c[2].weight, c[2].bias)
+
+
 def _reducer_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -157,6 +197,24 @@ def _reducer_worker(rank, world, port, out):
         p = dict(model.named_parameters())["classifier.0.weight"]
         off, n = opt.groups[0].offsets["classifier.0.weight"]
         assert torch.equal(p.grad.reshape(-1), opt.groups[0].g[off:off + n])
+    # the same exchange when the classifier gradients are written in place (no AccumulateGrad hook fires for them)
+    torch.manual_seed(0)
+    model2 = _TinyInPlace()
+    opt2 = FusedAdam(model2, 1e-3, 1e-3)
+    red2 = parallel.GradReducer(opt2, n_buckets=2)
+    assert len(model2.grad_callbacks) == 1
+    for it in range(2):
+        opt2.zero_grad()
+        model2(x).pow(2).sum().backward()
+        assert red2.fired, "in-place classifier gradients did not start the early bucket"
+        topt.zero_grad()
+        twin(x).pow(2).sum().backward()
+        ref = [a.clone() for a in topt.grad_arenas()]
+        red2.finish()
+        for r in ref:
+            dist.all_reduce(r)
+        for a, r in zip(opt2.grad_arenas(), ref):
+            assert torch.allclose(a, r, atol=1e-6), (it, (a - r).abs().max())
     if rank == 0:
         torch.save({"ok": torch.tensor(1)}, out)
     dist.barrier()
