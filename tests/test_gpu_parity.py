@@ -532,6 +532,36 @@ def test_umpr_r_small_batches_vs_oracle(dev, B, seed):
             check(f"small-batch grad {k} B{B}", p.grad, P[k].grad, atol=1e-6, rel_to_max=2e-3)
 
 
+@pytest.mark.parametrize("E", [300, 7])
+def test_embedding_widths_vs_oracle(dev, E):
+    """GloVe-300d (BASELINE.json configs[4] uses it) and an odd width that is not a multiple of the GEMM k-step: the
+    embedding gather feeds the GRU input projection for any E; control net included (review_net_only=False needs VGG, so
+    the text half is checked through UMPR-R plus the C-Net GRU inside test_control)."""
+    from oracle import umpr_ref as R
+    from umpr_amd.config import Config
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_batch, make_param_state
+    P = make_param_state(65, E, 700, 1, True, m_scale=0.05)
+    batch = make_batch(66, 3, 700, review_net_only=True)
+    cfg = Config(argv=[])
+    cfg.review_net_only = True
+    model = UMPR(cfg, P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    pred, loss = model(*batch)
+    loss.backward()
+    for k, p in P.items():
+        if k != "embedding.weight":
+            p.requires_grad_(True)
+    rp, rl = R.umpr_forward(P, batch, review_net_only=True, aten=True)
+    rl.backward()
+    check(f"E{E} pred", pred, rp, atol=1e-4)
+    check(f"E{E} loss", loss, rl, atol=1e-4)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            check(f"E{E} grad {k}", p.grad, P[k].grad, atol=1e-6, rel_to_max=2e-3)
+
+
 def test_full_size_properties(L, dev):
     """BASELINE.json sizes (64 images, 1280 sequences): properties that need no CPU reference.
     (1) the VGG16 output of an image does not depend on the batch it is in - bit for bit (tiles straddle images, the
