@@ -55,6 +55,17 @@ class ShardedLoader:
         return len(self.loader)
 
 
+class _Collate:
+    """Picklable collate (worker processes): src/dataset.py:173-182 via umpr_amd.data.batch_loader."""
+
+    def __init__(self, ignore_photos):
+        self.ignore_photos = ignore_photos
+
+    def __call__(self, samples):
+        from umpr_amd.data import batch_loader
+        return batch_loader(samples, self.ignore_photos)
+
+
 def run_real(config, rank, world, log):
     """main.py:64-99 of the reference: Word2vec -> Dataset -> DataLoader(collate) -> training -> test."""
     from torch.utils.data import DataLoader
@@ -62,7 +73,13 @@ def run_real(config, rank, world, log):
     d = config.data_dir
     photo_path, photo_json = os.path.join(d, 'photos'), os.path.join(d, 'photos.json')
     w2v = Word2vec(config.word2vec_file)
-    collate = lambda x: batch_loader(x, config.review_net_only)
+    collate = _Collate(config.review_net_only)
+    workers = max(0, int(getattr(config, "loader_workers", 0)))
+    # decode + resize + collate in worker processes, pinned staging buffers, batches prefetched ahead of the GPU; with
+    # loader_workers = 0 everything runs on the training thread, as in the reference (main.py:70-73)
+    dl = dict(collate_fn=collate, num_workers=workers, pin_memory=True)
+    if workers:
+        dl.update(prefetch_factor=2, persistent_workers=True)
     model = UMPR(config, w2v.embedding).to(config.device)
     model_path = config.model_path or f"./model/{os.path.basename(d.strip('/'))}.pt"
     os.makedirs(os.path.dirname(model_path) or '.', exist_ok=True)
@@ -72,20 +89,21 @@ def run_real(config, rank, world, log):
         valid_data = Dataset(os.path.join(d, 'valid.csv'), photo_json, photo_path, w2v, config)
         log(f'Training dataset contains {len(train_data)} samples.')
         g = torch.Generator().manual_seed(0)  # same shuffle on every rank
-        train_dlr = ShardedLoader(DataLoader(train_data, batch_size=config.batch_size, shuffle=True, generator=g,
-                                             collate_fn=collate), rank, world)
-        valid_dlr = ShardedLoader(DataLoader(valid_data, batch_size=config.batch_size, collate_fn=collate), rank, world)
+        train_dlr = ShardedLoader(DataLoader(train_data, batch_size=config.batch_size, shuffle=True, generator=g, **dl),
+                                  rank, world)
+        valid_dlr = ShardedLoader(DataLoader(valid_data, batch_size=config.batch_size, **dl), rank, world)
         training(train_dlr, valid_dlr, model, config, model_path, logger=logger, world=world, rank=rank)
     if os.path.exists(model_path):
         from umpr_amd.checkpoint import load_checkpoint
         load_checkpoint(model_path, model, map_location=config.device)
     test_data = Dataset(os.path.join(d, 'test.csv'), photo_json, photo_path, w2v, config)
-    test_dlr = ShardedLoader(DataLoader(test_data, batch_size=config.batch_size, collate_fn=collate), rank, world)
+    test_dlr = ShardedLoader(DataLoader(test_data, batch_size=config.batch_size, **dl), rank, world)
     log(f"Test end, test mse is {evaluate_mse(model, test_dlr):.6f}")
 
 
 def main():
-    extra = {"synthetic_batches": 20, "synthetic_vocab": 400003, "synthetic_emb": 50, "vgg_weights": "", "resume": ""}
+    extra = {"synthetic_batches": 20, "synthetic_vocab": 400003, "synthetic_emb": 50, "vgg_weights": "", "resume": "",
+             "loader_workers": 0}
     for k, v in extra.items():
         setattr(Config, k, v)
     config = Config()

@@ -70,3 +70,20 @@ def test_pad_reviews_and_missing_photo():
     ds = Dataset(os.path.join(ROOT, "train.csv"), os.path.join(ROOT, "photos.json"), os.path.join(ROOT, "photos"), w, Cfg())
     b = batch_loader([ds[0], ds[1]])
     assert tuple(b[6].shape) == (2, 1, 2, 3, 224, 224) and b[6].dtype == torch.float32
+
+
+def test_worker_processes_collate_identically():
+    """main.py's picklable collate in DataLoader worker processes (--loader_workers) yields the batches of the in-process
+    path, tensor for tensor."""
+    from torch.utils.data import DataLoader
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from main import _Collate
+    w = w2v()
+    ds = Dataset(os.path.join(ROOT, "train.csv"), os.path.join(ROOT, "photos.json"), os.path.join(ROOT, "photos"), w, Cfg())
+    a = list(DataLoader(ds, batch_size=3, collate_fn=_Collate(True), num_workers=0))
+    b = list(DataLoader(ds, batch_size=3, collate_fn=_Collate(True), num_workers=2))
+    assert len(a) == len(b) and len(a) >= 2
+    for x, y in zip(a, b):
+        for t, u in zip(x, y):
+            assert torch.equal(t, u)

@@ -560,8 +560,10 @@ class UMPR(nn.Module):
         device = self.embedding.weight.device
         if device.type != "cuda":
             raise RuntimeError("umpr_amd.UMPR runs on an MI355X only (no CPU fallback): move the module to a cuda device")
-        user_reviews, item_reviews, ui_reviews = [_c(v.to(device)) for v in (user_reviews, item_reviews, ui_reviews)]
-        photos, labels = [v.to(device) for v in (photos, labels)]
+        # pinned host batches (DataLoader(pin_memory=True)) upload asynchronously; the kernels follow on the same stream
+        user_reviews, item_reviews, ui_reviews = [_c(v.to(device, non_blocking=True))
+                                                  for v in (user_reviews, item_reviews, ui_reviews)]
+        photos, labels = [v.to(device, non_blocking=True) for v in (photos, labels)]
         labels = _c(labels.float())
         emb = self.embedding.weight
         B, S, L = user_reviews.shape
