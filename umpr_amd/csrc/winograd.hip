@@ -413,6 +413,123 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmParams p) {
         Mb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Tpad + wn * 64 + j * 32 + l31] = tot[i][j][r];
 }
 
+// Same GEMM with the operand tiles copied global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: no staging
+// registers, no ds_write, no address VALU).  Both stage images are lane-linear: U is stored in image order, and a V
+// stage is 32 rows of 128 contiguous floats, so one wave-instruction (64 lanes x 16 B) fills two unpadded 512-B rows.
+// Unpadded rows are conflict-free for the fragment reads (32 consecutive floats per half-wave).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(WinoGemmParams p) {
+  constexpr int LD = 128;
+  constexpr int TM = 2, TN = 2;
+  constexpr int KS = WK / 2;
+  constexpr int SFLUSH = 4;
+  __shared__ __attribute__((aligned(1024))) float As[2][WK * LD];
+  __shared__ __attribute__((aligned(1024))) float Bs[2][WK * LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const long TT = p.TT;
+  const int xcd = blockIdx.x & 7;
+  const long qq = blockIdx.x >> 3;
+  const int mt = (int)(qq % p.MT);
+  const long bt = (qq / p.MT) * 8 + xcd;
+  if (bt >= 16 * TT) return;
+  const int xi = (int)(bt / TT);
+  const long t0 = (bt % TT) * WBN;
+  const float* Ub = p.U + (((long)xi * p.MT + mt) * p.S) * (WK * WBM);
+  const float* Vb = p.V + (long)xi * (p.S * WK) * p.Tpad + t0;
+  // piece j (0..3) of this wave: 256 floats of the stage image at float offset (wave * 4 + j) * 256
+  const float* ga = Ub + wave * 1024 + lane * 4;
+  const float* gb = Vb + (long)(wave * 8 + half) * p.Tpad + l31 * 4;
+  const long bstep = 2 * p.Tpad;
+  // Issued by inline asm: through the builtin hipcc waits vmcnt(0) right after every DMA (it cannot prove that the
+  // DMA target and the fragment reads do not alias), which serialises the copy with the MFMAs.  M0 = LDS byte address
+  // of the piece (wave-uniform); the hardware adds lane * 16.  M0 is saved and restored around the instruction.
+  const unsigned lds_a = (unsigned)(size_t)(lds_ptr_t)(&As[0][0]) + (unsigned)wave * 4096u;
+  const unsigned lds_b = (unsigned)(size_t)(lds_ptr_t)(&Bs[0][0]) + (unsigned)wave * 4096u;
+  auto glds = [&](const float* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  auto dma = [&](int q, int sn, int nbuf) {   // q = 0..3: A pieces, 4..7: B pieces
+    if (q < 4) glds(ga + (long)sn * (WK * WBM) + q * 256, lds_a + (unsigned)nbuf * (WK * LD * 4u) + (unsigned)q * 1024u);
+    else glds(gb + (long)sn * WK * p.Tpad + (q - 4) * bstep, lds_b + (unsigned)nbuf * (WK * LD * 4u) + (unsigned)(q - 4) * 1024u);
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  f32x16 acc[TM][TN], tot[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+  const int ns = p.S;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dma(q, 0, 0);
+  dma_wait();
+  __syncthreads();
+  for (int s0 = 0; s0 < ns; s0 += SFLUSH) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int s1 = min(ns, s0 + SFLUSH);
+    for (int s = s0; s < s1; ++s) {
+      const int cur = s & 1;
+      const int sn = min(s + 1, ns - 1);
+      const float* as = As[cur] + half * LD + wm * 64 + l31;
+      const float* bs = Bs[cur] + half * LD + wn * 64 + l31;
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const int cb = kk & 1, nb = cb ^ 1;
+        const int k1 = kk + 1;
+#pragma unroll
+        for (int m = 0; m < TM * TN; ++m) {
+          const int i = m / TN, j = m % TN;
+          acc[i][j] = mfma32(a[cb][i], b[cb][j], acc[i][j]);
+          if (m == 0 && k1 < KS) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) a[nb][ii] = as[2 * k1 * LD + ii * 32];
+          }
+          if (m == 1 && k1 < KS) {
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) b[nb][jj] = bs[2 * k1 * LD + jj * 32];
+          }
+          if (m == 3 && kk < 8) dma(kk, sn, cur ^ 1);   // the other buffer: every wave left it at the last barrier
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      dma_wait();        // this wave's pieces of stage s + 1 have landed ...
+      __syncthreads();   // ... and after the barrier every wave's have
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
+  }
+  float* Mb = p.Mx + ((long)xi * p.Mpad + mt * WBM) * p.Tpad + t0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Mb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Tpad + wn * 64 + j * 32 + l31] = tot[i][j][r];
+}
+
+const bool g_wino_dma = [] { const char* v = getenv("UMPR_WINO_DMA"); return !(v && v[0] == '0'); }();
+
 inline int nblk(long n, int cap) {
   long b = (n + 255) / 256;
   if (b > cap) b = cap;
@@ -454,7 +571,8 @@ int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const floa
   const long groups = (16 * TT + 7) / 8 * 8;
   {
     UmprProfScope prof(UMPR_K_WINO_GEMM, 2.0 * 16 * (double)M * C * T, s);
-    wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+    if (g_wino_dma) wino_gemm_dma_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+    else wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_gemm");
   if ((W / 2) % 2 == 0)
