@@ -418,13 +418,15 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmParams p) {
 // stage is 32 rows of 128 contiguous floats, so one wave-instruction (64 lanes x 16 B) fills two unpadded 512-B rows.
 // Unpadded rows are conflict-free for the fragment reads (32 consecutive floats per half-wave).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-__global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(WinoGemmParams p) {
+template <int SK, int OCC>
+__global__ __launch_bounds__(256, OCC) void wino_gemm_dma_kernel(WinoGemmParams p) {
   constexpr int LD = 128;
   constexpr int TM = 2, TN = 2;
-  constexpr int KS = WK / 2;
-  constexpr int SFLUSH = 4;
-  __shared__ __attribute__((aligned(1024))) float As[2][WK * LD];
-  __shared__ __attribute__((aligned(1024))) float Bs[2][WK * LD];
+  constexpr int KS = SK / 2;            // MFMA k-steps per stage
+  constexpr int NP = SK / 8;            // 1-KiB DMA pieces per wave, operand and stage
+  constexpr int SFLUSH = 128 / SK;      // stages per MFMA accumulation chain (128 k)
+  __shared__ __attribute__((aligned(1024))) float As[2][SK * LD];
+  __shared__ __attribute__((aligned(1024))) float Bs[2][SK * LD];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -440,22 +442,22 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(WinoGemmParams p)
   const float* Ub = p.U + (((long)xi * p.MT + mt) * p.S) * (WK * WBM);
   const float* Vb = p.V + (long)xi * (p.S * WK) * p.Tpad + t0;
   // piece j (0..3) of this wave: 256 floats of the stage image at float offset (wave * 4 + j) * 256
-  const float* ga = Ub + wave * 1024 + lane * 4;
-  const float* gb = Vb + (long)(wave * 8 + half) * p.Tpad + l31 * 4;
+  const float* ga = Ub + wave * (NP * 256) + lane * 4;
+  const float* gb = Vb + (long)(wave * (2 * NP) + half) * p.Tpad + l31 * 4;
   const long bstep = 2 * p.Tpad;
   // Issued by inline asm: through the builtin hipcc waits vmcnt(0) right after every DMA (it cannot prove that the
   // DMA target and the fragment reads do not alias), which serialises the copy with the MFMAs.  M0 = LDS byte address
   // of the piece (wave-uniform); the hardware adds lane * 16.  M0 is saved and restored around the instruction.
-  const unsigned lds_a = (unsigned)(size_t)(lds_ptr_t)(&As[0][0]) + (unsigned)wave * 4096u;
-  const unsigned lds_b = (unsigned)(size_t)(lds_ptr_t)(&Bs[0][0]) + (unsigned)wave * 4096u;
+  const unsigned lds_a = (unsigned)(size_t)(lds_ptr_t)(&As[0][0]) + (unsigned)wave * (NP * 1024u);
+  const unsigned lds_b = (unsigned)(size_t)(lds_ptr_t)(&Bs[0][0]) + (unsigned)wave * (NP * 1024u);
   auto glds = [&](const float* src, unsigned dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
-  auto dma = [&](int q, int sn, int nbuf) {   // q = 0..3: A pieces, 4..7: B pieces
-    if (q < 4) glds(ga + (long)sn * (WK * WBM) + q * 256, lds_a + (unsigned)nbuf * (WK * LD * 4u) + (unsigned)q * 1024u);
-    else glds(gb + (long)sn * WK * p.Tpad + (q - 4) * bstep, lds_b + (unsigned)nbuf * (WK * LD * 4u) + (unsigned)(q - 4) * 1024u);
+  auto dma = [&](int q, int sn, int nbuf) {   // q = 0..NP-1: A pieces, NP..2NP-1: B pieces; sn counts SK-deep stages
+    if (q < NP) glds(ga + (long)sn * (SK * WBM) + q * 256, lds_a + (unsigned)nbuf * (SK * LD * 4u) + (unsigned)q * 1024u);
+    else glds(gb + (long)sn * SK * p.Tpad + (q - NP) * bstep, lds_b + (unsigned)nbuf * (SK * LD * 4u) + (unsigned)(q - NP) * 1024u);
   };
   auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
@@ -467,9 +469,9 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(WinoGemmParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
-  const int ns = p.S;
+  const int ns = p.S * (WK / SK);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) dma(q, 0, 0);
+  for (int q = 0; q < 2 * NP; ++q) dma(q, 0, 0);
   dma_wait();
   __syncthreads();
   for (int s0 = 0; s0 < ns; s0 += SFLUSH) {
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(WinoGemmParams p)
 #pragma unroll
             for (int jj = 0; jj < TN; ++jj) b[nb][jj] = bs[2 * k1 * LD + jj * 32];
           }
-          if (m == 3 && kk < 8) dma(kk, sn, cur ^ 1);   // the other buffer: every wave left it at the last barrier
+          if (m == 3 && kk < 2 * NP) dma(kk, sn, cur ^ 1);   // the other buffer: every wave left it at the last barrier
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(WinoGemmParams p)
         Mb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Tpad + wn * 64 + j * 32 + l31] = tot[i][j][r];
 }
 
-const bool g_wino_dma = [] { const char* v = getenv("UMPR_WINO_DMA"); return !(v && v[0] == '0'); }();
+const int g_wino_dma = [] { const char* v = getenv("UMPR_WINO_DMA"); return v ? atoi(v) : 1; }();   // 0 off, 1: 32-deep stages, 2: 16-deep stages at 3 waves/SIMD
 
 inline int nblk(long n, int cap) {
   long b = (n + 255) / 256;
@@ -571,7 +573,8 @@ int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const floa
   const long groups = (16 * TT + 7) / 8 * 8;
   {
     UmprProfScope prof(UMPR_K_WINO_GEMM, 2.0 * 16 * (double)M * C * T, s);
-    if (g_wino_dma) wino_gemm_dma_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+    if (g_wino_dma == 2) wino_gemm_dma_kernel<16, 3><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+    else if (g_wino_dma) wino_gemm_dma_kernel<32, 2><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
     else wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_gemm");
