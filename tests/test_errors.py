@@ -1,0 +1,85 @@
+"""Error behaviour of the boundary (INTEGRATION.md "Error behaviour"): the product path fails loudly - it never falls
+back to the CPU or to the oracle."""
+import os
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _cfg(**kw):
+    from umpr_amd.config import Config
+    cfg = Config(argv=[])
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def test_model_on_cpu_raises():
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_batch, make_param_state
+    P = make_param_state(1, 50, 100, 1, True)
+    model = UMPR(_cfg(review_net_only=True), P["embedding.weight"].numpy())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(*make_batch(2, 2, 100, review_net_only=True))
+
+
+def test_unsupported_hidden_size_raises():
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_param_state
+    P = make_param_state(1, 50, 100, 1, True)
+    with pytest.raises(AssertionError, match="gru_size"):
+        UMPR(_cfg(review_net_only=True, gru_size=32), P["embedding.weight"].numpy())
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    from umpr_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libumpr_hip.so"))
+    with pytest.raises(_lib.UmprHipError, match="no CPU fallback"):
+        _lib._Lib()
+
+
+def test_optimizer_step_on_cpu_raises():
+    from umpr_amd.optim import FusedAdam
+    opt = FusedAdam(torch.nn.Linear(3, 2), 1e-3, 1e-3)
+    with pytest.raises(RuntimeError, match="cuda"):
+        opt.step()
+
+
+def test_product_package_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    import re
+    pat = re.compile(r"^\s*(import\s+oracle|from\s+oracle)\b", re.M)
+    files = [os.path.join(ROOT, "main.py")]
+    for dirpath, _, names in os.walk(os.path.join(ROOT, "umpr_amd")):
+        files += [os.path.join(dirpath, f) for f in names if f.endswith(".py")]
+    assert len(files) > 8
+    for f in files:
+        assert not pat.search(open(f).read()), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert pat.search(bench) is None or "def cpu_baseline" in bench   # bench.py imports it inside cpu_baseline only
+    body = bench[bench.index("def cpu_baseline"):]
+    body = body[:body.index("\ndef ", 1)]
+    assert "oracle" in body and not pat.search(bench.replace(body, ""))
+
+
+@pytest.mark.gpu
+def test_c_abi_reports_errors():
+    """A too-small scratch buffer or an unsupported shape comes back as a non-zero return code with a message, surfaced
+    as UmprHipError - never as a silent fallback."""
+    from umpr_amd._lib import UmprHipError, lib
+    L = lib()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(1, 64, 28, 28, device=dev)
+    w = torch.zeros(64, 64, 3, 3, device=dev)
+    b = torch.zeros(64, device=dev)
+    y = torch.empty(1, 64, 28, 28, device=dev)
+    dw, db = torch.empty_like(w), torch.empty_like(b)
+    tiny = torch.empty(16, device=dev)
+    with pytest.raises(UmprHipError, match="workspace"):
+        L.call("umpr_conv3x3_bwd_weight", y, x, dw, db, 1, 64, 28, 28, 64, tiny, 64, st)
+    with pytest.raises(UmprHipError):
+        L.call("umpr_maxpool2_fwd", x, y, 64, 27, 27, st)   # odd extent
+    assert "maxpool2" in L.last_error()
