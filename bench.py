@@ -31,17 +31,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 
 GFLOP_PER_SAMPLE_TRAIN = 93.73  # SURVEY.md 8(d), cfg2 fully padded
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the conv forward/dgrad kernels from the committed rocprofv3 --pmc passes of this
-    build (profiles/README.md; FETCH_SIZE doubled per the guide's gfx950 correction), averaged over the 25 forward +
-    dgrad layer calls of a step (the same kernels; the counters are summed per kernel name).  bench.py cannot run the
-    counter passes itself, so the figure is the stored measurement, or None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
+def pmc_traffic(eval_mode):
+    """HBM-side bytes per launch of the conv forward family from the committed rocprofv3 --pmc passes
+    (profiles/README.md: `tools/pmc_traffic.sh --eval`, forward only so that every conv dispatch is a forward launch;
+    FETCH_SIZE doubled per the guide's gfx950 correction), averaged over the 13 forward layer calls of a step.
+    bench.py cannot run the counter passes itself, so the figure is the stored measurement, or None when absent."""
+    path = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic_fwd.json")
     try:
         d = json.load(open(path))
         f = d["families"]["igemm_family"]
         per_step = (2.0 * f["FETCH_SIZE"] + f["WRITE_SIZE"]) * 1024.0 / d["steps"]
-        return per_step / 25.0, "bytes/launch from profiles/r01_e_pmc_traffic.json (batch 64, 25 fwd+dgrad launches/step)"
+        return per_step / 13.0, "bytes/launch from profiles/r01_i_pmc_traffic_fwd.json (batch 64, 13 forward launches/step)"
     except Exception:
         return None, "no stored PMC pass"
 
@@ -200,7 +200,8 @@ def main():
         # Winograd layers execute 1/2.25 of the direct-convolution FLOPs `achieved` counts for them;
         # the same nine layers take the Winograd path in forward and in dgrad, so half of family 4's work is forward
         executed = (work - 1.25 * 0.5 * fam["wino_gemm"][1]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_note = pmc_traffic() if args.batch == 64 and not args.review_net_only else (None, "stored PMC pass is for batch 64")
+        traffic, traffic_note = (pmc_traffic(args.eval) if args.batch == 64 and args.views == 1 and not args.review_net_only
+                                 else (None, "stored PMC pass is for the batch-64, 1-view workload"))
         out = {
             "metric": "inference samples/sec" if args.eval else "training samples/sec", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,

@@ -1,10 +1,13 @@
 # HBM-side traffic of the conv kernels (rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes as the guide
 # prescribes), summed per kernel family over one bench run of 2 steps.  Writes gpurun_out/pmc_traffic.json.
+# usage: bash tools/pmc_traffic.sh [extra bench.py args, e.g. --eval: forward only, so that every conv dispatch in the
+# trace is a forward launch (forward, dgrad and the wgrad transforms share kernel names)]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+EXTRA="$@"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pt_$c
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pt_$c -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/pt_$c.out 2> /tmp/pt_$c.err || { echo "pass $c failed"; tail -5 /tmp/pt_$c.err; exit 1; }
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pt_$c -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline $EXTRA > /tmp/pt_$c.out 2> /tmp/pt_$c.err || { echo "pass $c failed"; tail -5 /tmp/pt_$c.err; exit 1; }
 done
 python3 - <<'PY'
 import csv, glob, json, os, collections
