@@ -102,7 +102,10 @@ def test_gemm(L, dev, M, N, K, ta, tb):
                                           (1, 3, 64, 224), (2, 8, 16, 112), (3, 16, 32, 56), (5, 12, 130, 28),
                                           (7, 6, 64, 14), (3, 130, 70, 14),
                                           # >= 32 reduction channels on 56/28/14 maps: Winograd F(2x2,3x3) path
-                                          (2, 64, 96, 56), (3, 40, 200, 28), (5, 256, 256, 14), (1, 512, 512, 14)])
+                                          (2, 64, 96, 56), (3, 40, 200, 28), (5, 256, 256, 14), (1, 512, 512, 14),
+                                          # channel counts off the 32 / 128 tile grid, odd batch sizes, one image
+                                          (4, 33, 65, 28), (7, 100, 36, 14), (2, 129, 257, 14), (1, 32, 32, 56),
+                                          (3, 48, 160, 56)])
 def test_conv3x3(L, dev, N, Cin, Cout, HW):
     g = torch.Generator().manual_seed(N + Cin + Cout + HW)
     x = torch.randn(N, Cin, HW, HW, generator=g)
