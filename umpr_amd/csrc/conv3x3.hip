@@ -992,6 +992,73 @@ __global__ void maxpool2_bwd_relu_kernel(const float* __restrict__ x, const floa
 // ---- internal host entry points ------------------------------------------------------------------------------
 static bool g_conv_no_wino = false;  // UMPR_CONV_WINO=0 keeps the deep layers on the direct kernel (A/B runs)
 static int g_conv_bn = 0;  // UMPR_CONV_BN: 0 auto (128x128 bulk + 128x64 tail), 128 or 64 force one tile shape (A/B runs)
+// ---- first layer (Cin <= 3): no LDS, no barriers.  K = 27 is too short for the staged kernels (they pad it to a
+// 144-deep stage and become MFMA-bound on zeros); here every wave keeps its weight fragments in registers for the
+// whole launch and walks over 32-pixel tiles: 14 gathered loads per lane (image planes stay in L2), 14 MFMA k-steps
+// for each 32-channel block, +bias, ReLU, 128-B row-segment stores.  The launch is bound by the output write.
+template <int TM>   // TM = Cout / 32
+__global__ __launch_bounds__(256) void conv3x3_fwd_c3_kernel(ConvParams p) {
+  constexpr int KS = 14;   // k = 2 * kk + half < 28; k = c * 9 + tap, k >= C * 9 contributes zero
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  const int KR = p.C * 9;
+  float wa[TM][KS];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int k = 2 * kk + half;
+      wa[i][kk] = k < KR ? p.wm[(long)(i * 32 + l31) * KR + k] : 0.f;
+    }
+  float bv[TM][16];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[i][r] = p.bias ? p.bias[i * 32 + mfma_row(r, lane)] : 0.f;
+  const long HW = (long)p.H * p.W;
+  const long ntiles = (p.p_end + 31) / 32;
+  for (long t = wave; t < ntiles; t += nwaves) {
+    const long px = t * 32 + l31;
+    const bool okp = px < p.p_end;
+    const long pc = okp ? px : 0;
+    const int n = (int)(pc / HW);
+    const int rem = (int)(pc - (long)n * HW);
+    const int y = rem / p.W, x = rem - y * p.W;
+    const float* img = p.x + (long)n * p.C * HW;
+    float b[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int k = 2 * kk + half;
+      const int c = k / 9, tap = k - c * 9;
+      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+      const bool ok = okp && k < KR && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      const float v = img[ok ? (long)c * HW + (long)yy * p.W + xx : 0];
+      b[kk] = ok ? v : 0.f;
+    }
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = bv[i][r];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = mfma32(wa[i][kk], b[kk], acc[i]);
+    if (okp) {
+      float* out = p.y + (long)n * p.Cout * HW + rem;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][r];
+          if (p.relu) v = fmaxf(v, 0.f);
+          out[(long)(i * 32 + mfma_row(r, lane)) * HW] = v;
+        }
+    }
+  }
+}
+
 static bool g_conv_force_v1 = false;  // UMPR_CONV_V1=1 selects the generic gather kernel (A/B runs)
 static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; const char* q = getenv("UMPR_CONV_BN"); g_conv_bn = q ? atoi(q) : 0; const char* wq = getenv("UMPR_CONV_WINO"); g_conv_no_wino = wq && wq[0] == '0'; } } g_conv_env_init;
 static bool wino_layer(int H, int W) { return H == W && (W == 56 || W == 28 || W == 14); }
@@ -1031,6 +1098,13 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
     // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs; timed under the same family with the direct conv's FLOP count
     UmprProfScope prof(transposed ? UMPR_K_CONV_DGRAD : UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
     return umpr_wino_conv3x3(x, w, transposed, bias, mask, y, N, Cin, Cout, H, W, relu, wpack, wpack_floats, s);
+  }
+  if (!transposed && Cin <= 3 && Cout == 64 && !mask && !g_conv_force_v1) {
+    ConvParams p{x, w, bias, nullptr, y, N, Cin, H, W, Cout, relu, 0, NP};
+    UmprProfScope prof(UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
+    conv3x3_fwd_c3_kernel<2><<<2048, 256, 0, s>>>(p);
+    UMPR_LAUNCH_CHECK("conv3x3_fwd_c3");
+    return 0;
   }
   const bool v2 = H == W && !g_conv_force_v1 && wpack && (W == 224 || W == 112 || W == 56 || W == 28 || W == 14);
   if (v2) {
