@@ -87,3 +87,35 @@ def test_worker_processes_collate_identically():
     for x, y in zip(a, b):
         for t, u in zip(x, y):
             assert torch.equal(t, u)
+
+
+def test_resize_bilinear_follows_the_cv2_recipe():
+    """resize_bilinear_u8 (OpenCV's 8-bit INTER_LINEAR restated): identity at equal size, constants stay constant, a
+    horizontal ramp is reproduced to 1 grey level, and the result stays within 1 level of float bilinear sampling at
+    half-pixel centres (the fixed-point rounding)."""
+    from umpr_amd.data import resize_bilinear_u8
+    g = np.random.default_rng(0)
+    img = g.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(resize_bilinear_u8(img, (53, 37)), img)
+    flat = np.full((40, 60, 3), 77, np.uint8)
+    assert np.array_equal(resize_bilinear_u8(flat, (224, 224)), np.full((224, 224, 3), 77, np.uint8))
+    big = g.integers(0, 256, (375, 500, 3), dtype=np.uint8)
+    out = resize_bilinear_u8(big, (224, 224))
+    assert out.shape == (224, 224, 3) and out.dtype == np.uint8
+
+    def ref(src, dw, dh):   # float bilinear, same tap rule
+        h, w, _ = src.shape
+        fx = (np.arange(dw) + 0.5) * w / dw - 0.5
+        fy = (np.arange(dh) + 0.5) * h / dh - 0.5
+        x0 = np.floor(fx).astype(int); ax = fx - x0
+        ax = np.where((x0 < 0) | (x0 >= w - 1), 0.0, ax)
+        x0 = np.clip(x0, 0, w - 1); x1 = np.minimum(x0 + 1, w - 1)
+        y0 = np.floor(fy).astype(int); ay = fy - y0
+        y1 = np.clip(y0 + 1, 0, h - 1); y0 = np.clip(y0, 0, h - 1)
+        s = src.astype(np.float64)
+        rows = s[:, x0] * (1 - ax)[None, :, None] + s[:, x1] * ax[None, :, None]
+        return rows[y0] * (1 - ay)[:, None, None] + rows[y1] * ay[:, None, None]
+
+    assert np.abs(out.astype(np.float64) - ref(big, 224, 224)).max() <= 1.0
+    up = resize_bilinear_u8(img, (224, 224))
+    assert np.abs(up.astype(np.float64) - ref(img, 224, 224)).max() <= 1.0

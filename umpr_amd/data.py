@@ -9,10 +9,11 @@
 * ``pad_reviews`` / ``batch_loader`` - the collate that produces the 8-tensor batch ``UMPR.forward`` consumes
   (src/dataset.py:122-182): batch-wide common (count, length) for user and item, independent padding for ui, pad id 0,
   empty sentences get length 1.
-* ``get_image`` - JPEG -> float32 CHW RGB in [0,1], 224x224 (src/dataset.py:134-143).  The reference decodes with
-  cv2 (INTER_LINEAR resize); cv2 is not installed here, PIL's bilinear resize is used instead - pixel values can
-  differ in the last bits from cv2's ("parity unpinned" for the resize; unreadable files become zeros like the
-  reference).
+* ``get_image`` - JPEG -> CHW RGB in [0,1], 224x224 (src/dataset.py:134-143).  The reference decodes and resizes with
+  cv2, which is not installed here: the file is decoded with PIL and resized by ``resize_bilinear_u8``, a restatement
+  of OpenCV's 8-bit INTER_LINEAR (2 taps at half-pixel centres, 11-bit fixed-point weights - PIL's own BILINEAR
+  antialiases when shrinking and would give different pictures).  Unpinned against cv2 itself ("parity unpinned" for
+  decode + resize); unreadable files become zeros like the reference.
 
 Everything here runs on the host; tensors come out in the layout the kernels expect.
 """
@@ -171,12 +172,51 @@ def pad_reviews(reviews, max_count=None, max_len=None, pad=0):
     return padded, lengths
 
 
+def _linear_coeffs(dst, src):
+    """Source index pairs and 11-bit fixed-point weights of OpenCV's 8-bit INTER_LINEAR resize along one axis
+    (half-pixel centres: f = (d + 0.5) * src / dst - 0.5; weights cvRound(w * 2048))."""
+    f = (np.arange(dst, dtype=np.float64) + 0.5) * (src / dst) - 0.5
+    f = f.astype(np.float32)                       # OpenCV keeps the coordinate in a float
+    s = np.floor(f).astype(np.int64)
+    w = (f - s).astype(np.float32)
+    return s, w
+
+
+def resize_bilinear_u8(img, size):
+    """cv2.resize(img, size) for uint8 HxWxC with the default INTER_LINEAR, restated from OpenCV's fixed-point path
+    (resize.cpp: HResizeLinear / VResizeLinear for uchar - 2 taps, no antialiasing, coefficients scaled by 2^11):
+    horizontally, taps left of column 0 or right of the last column collapse onto the edge pixel with weight 1;
+    vertically the row indices are clipped.  cv2 is not installed here, so this is unpinned against cv2 itself; it is
+    what the reference's get_image computes by construction, where PIL's own BILINEAR filter would antialias."""
+    dw, dh = size
+    h, w, _ = img.shape
+    sx, fx = _linear_coeffs(dw, w)
+    fx = np.where((sx < 0) | (sx >= w - 1), np.float32(0), fx)
+    sx = np.clip(sx, 0, w - 1)
+    sx1 = np.minimum(sx + 1, w - 1)
+    a1 = np.rint(fx * np.float32(2048)).astype(np.int32)
+    a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int32)
+    sy, fy = _linear_coeffs(dh, h)
+    b1 = np.rint(fy * np.float32(2048)).astype(np.int32)
+    b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(np.int32)
+    y0 = np.clip(sy, 0, h - 1)
+    y1 = np.clip(sy + 1, 0, h - 1)
+    used = np.unique(np.concatenate([y0, y1]))                     # only the source rows some output row taps
+    src = np.ascontiguousarray(np.take(img, used, axis=0).transpose(2, 0, 1)).astype(np.int32)   # [c][rows][w]
+    rows = np.take(src, sx, axis=2) * a0 + np.take(src, sx1, axis=2) * a1                         # scaled by 2^11
+    rows >>= 4
+    r0 = np.take(rows, np.searchsorted(used, y0), axis=1)          # [c][dh][dw]
+    r1 = np.take(rows, np.searchsorted(used, y1), axis=1)
+    out = (((b0[None, :, None] * r0) >> 16) + ((b1[None, :, None] * r1) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8).transpose(1, 2, 0)
+
+
 def get_image(path, resize=(224, 224)):
     try:
         from PIL import Image
         with Image.open(path) as im:
-            im = im.convert('RGB').resize(resize, Image.BILINEAR)
-            a = np.asarray(im, dtype=np.float64).transpose(2, 0, 1) / 255.0
+            rgb = np.asarray(im.convert('RGB'), dtype=np.uint8)    # cv2.imread + BGR2RGB, resized channel-wise
+        a = resize_bilinear_u8(rgb, resize).astype(np.float64).transpose(2, 0, 1) / 255.0
         return a
     except Exception:
         return np.zeros([3] + list(resize))
