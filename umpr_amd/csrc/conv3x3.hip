@@ -8,6 +8,9 @@
 //  wgrad           : per workgroup a 64(cout) x 64(cin) x 9(tap) tile, K = pixels; the gz tile and the x halo patch
 //                    of a 32-pixel segment are staged once in LDS and serve all nine taps (9 accumulator tiles per
 //                    wave).  Split-K over pixel segments into slabs [split][tap][cout][cin] + deterministic reduce.
+//  dispatch        : umpr_conv3x3_run / umpr_conv3x3_wgrad pick, per layer shape: the first-layer forward kernel
+//                    (Cin <= 3), the Winograd kernels of winograd.hip (56 / 28 / 14 maps with >= 32 channels), the
+//                    LDS-patch implicit GEMM below (VGG map widths), or the generic gather kernel (any other shape).
 #include "umpr_common.h"
 #include "umpr_internal.h"
 #include "umpr_tiles.h"
