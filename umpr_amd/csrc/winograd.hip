@@ -1,17 +1,16 @@
-// Winograd F(2x2,3x3) path for the deep VGG16 layers (56x56, 28x28, 14x14 maps), forward and data gradient, fp32.
+// Winograd path for the deep VGG16 layers (56x56, 28x28, 14x14 maps), fp32.
 //
-//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile / 4x4 input tile / channel pair
-//
-// 16 independent GEMMs  M[xi][m][t] = sum_c U[xi][m][c] * V[xi][c][t]  (t = tile index over the batch) replace the
-// 9-tap implicit GEMM: 2.25x fewer MFMA FLOPs.  Three kernels per layer call:
-//   wino_input_kernel  : x -> V   (HBM bound: reads |x|, writes 4|x|)
-//   wino_gemm_kernel   : batched GEMM on v_mfma_f32_32x32x2_f32, same structure as conv3x3_igemm_v2 (LDS double
-//                        buffer, fragment prefetch pinned one step ahead, staging pieces between MFMAs, 2-level
-//                        accumulation, XCD-aware tile order); weights arrive pre-laid-out in the LDS image order
-//   wino_output_kernel : M -> y   with the fused epilogue (+bias, ReLU) or (dgrad) * [mask > 0]
-// plus wino_weights_kernel (U = G g G^T, for dgrad on the flipped, channel-transposed kernel).
-// The shallow layers (224, 112) stay on the direct kernel: there the 16x activation-sized transform traffic costs
-// more than the MFMA time it saves.  Weight gradients stay on the direct wgrad kernel.
+// Forward and data gradient, F(2x2,3x3):   Y = A^T [ (G g G^T) .* (B^T d B) ] A   per 2x2 output tile / 4x4 input tile
+//   16 independent GEMMs  M[xi][m][t] = sum_c U[xi][m][c] * V[xi][c][t]  (t = tile index over the batch) replace the
+//   9-tap implicit GEMM: 2.25x fewer MFMA FLOPs.  Kernels per layer call:
+//     wino_weights_kernel      : U = G g G^T (for dgrad on the flipped, channel-transposed kernel), LDS image order
+//     wino_input[_pair]_kernel : x -> V   (HBM bound: reads |x|, writes 4|x|; zero-pads channels / tiles to the GEMM tile)
+//     wino_gemm_dma_kernel     : batched GEMM on v_mfma_f32_32x32x2_f32, operands copied global -> LDS by LDS-DMA
+//                                (wino_gemm_kernel: the same loop staged through registers, UMPR_WINO_DMA=0)
+//     wino_output[_pair]_kernel: M -> y   with the fused epilogue (+bias, ReLU) or (dgrad) * [mask > 0]
+// Weight gradient, F(3x3,2x2): see the second half of this file (wino_dy / wino_wgrad_gemm / wino_wgrad_finish).
+// The shallow layers (224, 112) stay on the direct kernels of conv3x3.hip: there the 16x activation-sized transform
+// traffic costs more than the MFMA time it saves.
 #include "umpr_common.h"
 #include "umpr_internal.h"
 
