@@ -176,12 +176,12 @@ def capture(model, store):
 
 
 def gen_umpr(refmodel, name, *, B, n_views, review_net_only, m_scale, pseed, bseed, full_pad=False,
-             drop_masks=False, vocab=1000):
+             drop_masks=False, vocab=1000, photo_count=1):
     P = make_param_state(pseed, 50, vocab, n_views, review_net_only, m_scale=m_scale)
-    batch = make_batch(bseed, B, vocab, n_views, review_net_only=review_net_only, full_pad=full_pad)
+    batch = make_batch(bseed, B, vocab, n_views, photo_count, review_net_only=review_net_only, full_pad=full_pad)
     model = build_reference(refmodel, P, review_net_only, n_views)
     out = dict(meta=np.array([B, n_views, int(review_net_only), pseed, bseed, int(full_pad), vocab], dtype=np.int64),
-               m_scale=np.array(m_scale))
+               m_scale=np.array(m_scale), photo_count=np.array(photo_count))
     if drop_masks:
         model.train()
         g = torch.Generator().manual_seed(bseed + 1000)
@@ -419,6 +419,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
         gen_dataset()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "photos":
+        gen_umpr(refmodel, "umpr_full_V2_P2_B2", B=2, n_views=2, review_net_only=False, m_scale=0.05, pseed=59,
+                 bseed=60, photo_count=2)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "pretrain":
         gen_pretrain_rnet()
         return
@@ -436,6 +440,8 @@ def main():
     gen_umpr(refmodel, "umpr_full_V1_B2_drop", B=2, n_views=1, review_net_only=False, m_scale=0.05, pseed=57, bseed=58,
              drop_masks=True)
     gen_pretrain_rnet()
+    gen_umpr(refmodel, "umpr_full_V2_P2_B2", B=2, n_views=2, review_net_only=False, m_scale=0.05, pseed=59, bseed=60,
+             photo_count=2)
 
 
 if __name__ == "__main__":

@@ -397,7 +397,8 @@ def _build(gname, dev):
     g = load_golden(gname)
     B, V, ronly, pseed, bseed, full_pad, vocab = [int(v) for v in g["meta"]]
     P = make_param_state(pseed, 50, vocab, V, bool(ronly), m_scale=float(g["m_scale"]))
-    batch = make_batch(bseed, B, vocab, V, review_net_only=bool(ronly), full_pad=bool(full_pad))
+    batch = make_batch(bseed, B, vocab, V, int(g["photo_count"]) if "photo_count" in g else 1,
+                       review_net_only=bool(ronly), full_pad=bool(full_pad))
     cfg = Config(argv=[])
     cfg.review_net_only = bool(ronly)
     cfg.views = ["v%d" % i for i in range(V)]
@@ -443,7 +444,8 @@ def test_umpr_r_golden(dev, name):
     _compare_golden(g, model, pred, loss)
 
 
-@pytest.mark.parametrize("name", ["umpr_full_V1_B2", "umpr_full_V1_B2_randnM", "umpr_full_V4_B2", "umpr_full_V1_B2_drop"])
+@pytest.mark.parametrize("name", ["umpr_full_V1_B2", "umpr_full_V1_B2_randnM", "umpr_full_V4_B2", "umpr_full_V1_B2_drop",
+                                  "umpr_full_V2_P2_B2"])
 def test_umpr_full_golden(dev, name):
     g, model, batch = _build(name, dev)
     log(f"== {name}")

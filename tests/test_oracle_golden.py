@@ -47,7 +47,8 @@ def _run(name, aten=False):
     for k, p in P.items():
         if k != "embedding.weight":
             p.requires_grad_(True)
-    batch = make_batch(bseed, B, vocab, V, review_net_only=bool(ronly), full_pad=bool(full_pad))
+    batch = make_batch(bseed, B, vocab, V, int(g["photo_count"]) if "photo_count" in g else 1,
+                       review_net_only=bool(ronly), full_pad=bool(full_pad))
     masks = None
     if "drop_mask0" in g:
         masks = [t(g["drop_mask0"]).float(), t(g["drop_mask1"]).float()]
@@ -83,7 +84,8 @@ def test_umpr_r(name, aten):
     _check(*_run(name, aten))
 
 
-@pytest.mark.parametrize("name", ["umpr_full_V1_B2", "umpr_full_V1_B2_randnM", "umpr_full_V4_B2", "umpr_full_V1_B2_drop"])
+@pytest.mark.parametrize("name", ["umpr_full_V1_B2", "umpr_full_V1_B2_randnM", "umpr_full_V4_B2", "umpr_full_V1_B2_drop",
+                                  "umpr_full_V2_P2_B2"])
 def test_umpr_full(name):
     _check(*_run(name, aten=True))
 
