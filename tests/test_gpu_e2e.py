@@ -148,6 +148,22 @@ def test_main_cli_on_csv_corpus(tmp_path, capsys, monkeypatch):
     assert "Initial validation mse is" in out and "Test end, test mse is" in out, out[-2000:]
     mse = float(out.strip().split("test mse is")[-1])
     assert mse == mse and mse < 100.0
+    # --test_only (main.py:87-99 of the reference): load the saved weights, no training, report the test MSE
+    from umpr_amd.checkpoint import save_checkpoint
+    from umpr_amd.data import Word2vec
+    from umpr_amd.model import UMPR
+    from umpr_amd.config import Config
+    cfg = Config(argv=argv[1:])
+    w2v = Word2vec(os.path.join(CORPUS, "glove.txt"))
+    torch.manual_seed(3)
+    m = UMPR(cfg, w2v.embedding)
+    save_checkpoint(str(tmp_path / "m.pt"), m)
+    monkeypatch.setattr(sys, "argv", argv + ["--test_only", "True"])
+    main.main()
+    out2 = capsys.readouterr().out
+    assert "Initial validation mse" not in out2 and "Test end, test mse is" in out2, out2[-2000:]
+    mse2 = float(out2.strip().split("test mse is")[-1])
+    assert mse2 == mse2 and mse2 != mse      # the freshly initialised weights of the checkpoint, not the trained ones
 
 
 @pytest.mark.parametrize("review_net_only", [True, False])
@@ -207,3 +223,30 @@ def test_in_place_gradients_keep_accumulation_semantics(dev):
     assert float(params[names[2]].grad.abs().max()) == 0.0
     # zero gradient: the first Adam step moves a weight by at most lr * (wd * |w|-driven update) <= lr
     assert float((params[names[2]].detach() - before).abs().max()) <= 1.001e-3
+
+
+def test_training_driver_validates_and_checkpoints_every_500_batches(dev, tmp_path):
+    """umpr_amd.train.training mirrors main.py:16-61: validation before training, again every 500 batches, a checkpoint
+    whenever the validation MSE improves on the best so far (which starts at 100), ExponentialLR per epoch."""
+    from umpr_amd.checkpoint import load_checkpoint
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import evaluate_mse, training
+    P = make_param_state(151, 50, 300, 1, True, m_scale=0.05)
+    cfg = _cfg(review_net_only=True, train_epochs=2, learning_rate=1e-3, lr_decay=0.5)
+    model = UMPR(cfg, P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    model = model.to(dev)
+    train = [make_batch(160 + i % 7, 2, 300, review_net_only=True, max_sent_count=6, min_sent_count=5) for i in range(260)]
+    valid = [make_batch(170, 4, 300, review_net_only=True, max_sent_count=6, min_sent_count=5)]
+    path = str(tmp_path / "best.pt")
+    lines = []
+    opt = training(train, valid, model, cfg, path, logger=type("L", (), {"info": staticmethod(lines.append)}))
+    assert lines[0].startswith("Initial validation mse is")
+    assert sum("batch   500" in ln for ln in lines) == 1                 # 2 epochs x 260 batches: one 500-batch mark
+    assert sum(ln.startswith("Epoch") and "done" in ln for ln in lines) == 2
+    assert abs(opt.lr - 1e-3 * 0.25) < 1e-12                             # two ExponentialLR steps
+    assert os.path.exists(path)
+    meta = load_checkpoint(path, model, opt, map_location=dev)            # the state at batch 500
+    assert meta["batch_counter"] == 500 and meta["best_loss"] < 100
+    assert abs(evaluate_mse(model, valid) - meta["best_loss"]) < 1e-6
