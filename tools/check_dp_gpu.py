@@ -75,6 +75,20 @@ def main():
             worst = max(worst, d / (float(c.abs().max()) + 1e-30))
             assert torch.allclose(a, c, rtol=1e-6, atol=1e-9), (k, d)
         print(f"data-parallel parameters equal the sequential replay (worst relative difference {worst:.2e})", flush=True)
+    # evaluation: every rank scores its shard, (sum of squared errors, count) are all-reduced (src/evaluate.py:6-14)
+    from umpr_amd.train import evaluate_mse
+    mse = evaluate_mse(model, [parallel.shard_batch(b, rank, world) for b in steps])
+    if rank == 0:
+        se, n = 0.0, 0
+        with torch.no_grad():   # shard by shard: the reference's sentence permutation couples the samples of a batch
+            for b in steps:     # (SURVEY.md header fact 1), so a shard's predictions are not the full batch's
+                for r in range(world):
+                    sh = parallel.shard_batch(b, r, world)
+                    pred, _ = model(*sh)
+                    se += float(((pred.cpu() - sh[-1]) ** 2).sum())
+                    n += len(pred)
+        assert abs(mse - se / n) < 1e-5, (mse, se / n)
+        print(f"two-rank evaluate_mse {mse:.6f} == single-process {se / n:.6f}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
