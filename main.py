@@ -104,8 +104,7 @@ def run_real(config, rank, world, log):
 def main():
     extra = {"synthetic_batches": 20, "synthetic_vocab": 400003, "synthetic_emb": 50, "vgg_weights": "", "resume": "",
              "loader_workers": 0}
-    for k, v in extra.items():
-        setattr(Config, k, v)
+    Config.extend(extra)
     config = Config()
     rank, local, world = parallel.init_distributed()
     if not torch.cuda.is_available():
