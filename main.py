@@ -42,14 +42,21 @@ class SyntheticLoader:
 
 
 class ShardedLoader:
-    """DataLoader whose batches are cut to this rank's contiguous chunk (DataParallel's scatter)."""
+    """DataLoader whose collate already cut every batch to this rank's contiguous chunk (DataParallel's scatter,
+    main.py:82) - see umpr_amd.data.batch_loader(shard=...): indices are sharded BEFORE the photos are decoded.  Yields
+    parallel.Shard tuples: the 8 tensors plus `.n_active`; a chunk may be empty when the last batch is short."""
 
     def __init__(self, loader, rank, world):
         self.loader, self.rank, self.world = loader, rank, world
 
     def __iter__(self):
         for b in self.loader:
-            yield parallel.shard_batch(b, self.rank, self.world) if self.world > 1 else b
+            if self.world <= 1:
+                yield b
+                continue
+            s = parallel.Shard(b[:8])
+            s.n_active = int(b[8])
+            yield s
 
     def __len__(self):
         return len(self.loader)
@@ -58,22 +65,40 @@ class ShardedLoader:
 class _Collate:
     """Picklable collate (worker processes): src/dataset.py:173-182 via umpr_amd.data.batch_loader."""
 
-    def __init__(self, ignore_photos):
+    def __init__(self, ignore_photos, rank=0, world=1):
         self.ignore_photos = ignore_photos
+        self.shard = (rank, world) if world > 1 else None
 
     def __call__(self, samples):
         from umpr_amd.data import batch_loader
-        return batch_loader(samples, self.ignore_photos)
+        return batch_loader(samples, self.ignore_photos, shard=self.shard)
+
+
+def _agree(value, rank):
+    """Rank 0's value on every rank (a timestamped default path must be the same file everywhere)."""
+    if parallel.active():
+        box = [value if rank == 0 else None]
+        torch.distributed.broadcast_object_list(box, src=0)
+        return box[0]
+    return value
 
 
 def run_real(config, rank, world, log):
     """main.py:64-99 of the reference: Word2vec -> Dataset -> DataLoader(collate) -> training -> test."""
     from torch.utils.data import DataLoader
-    from umpr_amd.data import Dataset, Word2vec, batch_loader
+    from umpr_amd.checkpoint import load_checkpoint
+    from umpr_amd.data import Dataset, Word2vec
     d = config.data_dir
     photo_path, photo_json = os.path.join(d, 'photos'), os.path.join(d, 'photos.json')
+    # like the reference (main.py:116-119) the default checkpoint name carries the start time, so a run that never
+    # saves cannot pick up an older run's file in its test phase
+    model_path = config.model_path or _agree(
+        f"./model/{os.path.basename(d.strip('/'))}{time.strftime('%Y%m%d_%H%M%S')}.pt", rank)
+    if config.test_only and not os.path.exists(model_path):
+        log(f'{model_path} is not exist! (--test_only needs --model_path <trained checkpoint>)')
+        sys.exit(-1)                                   # the reference exits here too (main.py:89-91)
     w2v = Word2vec(config.word2vec_file)
-    collate = _Collate(config.review_net_only)
+    collate = _Collate(config.review_net_only, rank, world)
     workers = max(0, int(getattr(config, "loader_workers", 0)))
     # decode + resize + collate in worker processes, pinned staging buffers, batches prefetched ahead of the GPU; with
     # loader_workers = 0 everything runs on the training thread, as in the reference (main.py:70-73)
@@ -81,9 +106,9 @@ def run_real(config, rank, world, log):
     if workers:
         dl.update(prefetch_factor=2, persistent_workers=True)
     model = UMPR(config, w2v.embedding).to(config.device)
-    model_path = config.model_path or f"./model/{os.path.basename(d.strip('/'))}.pt"
     os.makedirs(os.path.dirname(model_path) or '.', exist_ok=True)
     logger = None if rank else type('L', (), {'info': staticmethod(log)})
+    saved = False
     if not config.test_only:
         train_data = Dataset(os.path.join(d, 'train.csv'), photo_json, photo_path, w2v, config)
         valid_data = Dataset(os.path.join(d, 'valid.csv'), photo_json, photo_path, w2v, config)
@@ -92,18 +117,38 @@ def run_real(config, rank, world, log):
         train_dlr = ShardedLoader(DataLoader(train_data, batch_size=config.batch_size, shuffle=True, generator=g, **dl),
                                   rank, world)
         valid_dlr = ShardedLoader(DataLoader(valid_data, batch_size=config.batch_size, **dl), rank, world)
-        training(train_dlr, valid_dlr, model, config, model_path, logger=logger, world=world, rank=rank)
-    if os.path.exists(model_path):
-        from umpr_amd.checkpoint import load_checkpoint
+        _, saved = training(train_dlr, valid_dlr, model, config, model_path, logger=logger, world=world, rank=rank)
+    if config.test_only or saved:
         load_checkpoint(model_path, model, map_location=config.device)
+        log(f'Testing the checkpoint {model_path}')
+    else:
+        log('No checkpoint was written in this run (validation never improved at a multiple of the validation '
+            'interval): testing the model as it stands at the end of training')
     test_data = Dataset(os.path.join(d, 'test.csv'), photo_json, photo_path, w2v, config)
     test_dlr = ShardedLoader(DataLoader(test_data, batch_size=config.batch_size, **dl), rank, world)
     log(f"Test end, test mse is {evaluate_mse(model, test_dlr):.6f}")
 
 
 def main():
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # A rank that dies inside a step leaves its peers blocked in the next RCCL collective: report, then leave with a
+        # non-zero status at once (no orderly teardown that would itself wait for the peers) so that the launcher
+        # (torch.distributed.run) tears the job down.
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        if parallel.active():
+            os._exit(1)
+        raise
+
+
+def _main():
     extra = {"synthetic_batches": 20, "synthetic_vocab": 400003, "synthetic_emb": 50, "vgg_weights": "", "resume": "",
-             "loader_workers": 0}
+             "loader_workers": 0, "valid_every": 500, "dtype": "fp32"}
     Config.extend(extra)
     config = Config()
     rank, local, world = parallel.init_distributed()

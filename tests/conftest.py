@@ -17,6 +17,36 @@ def pytest_configure(config):
     config.addinivalue_line("filterwarnings", "ignore:The argument 'device' of Tensor:DeprecationWarning")
 
 
+# ---- two-rank data-parallel check on real kernels (tools/check_dp_gpu.py) ---------------------------------------
+# A process that has initialised the GPU must not fork+exec another GPU program on this pool, so the two-rank job is
+# started here, at session start, BEFORE anything in this process touches the GPU; tests/test_gpu_e2e.py collects it.
+DP_CHECK = {"proc": None, "log": os.path.join(ROOT, "gpurun_out", "dp_check.log")}
+
+
+def pytest_sessionstart(session):
+    import subprocess
+    mexpr = session.config.getoption("-m") or ""
+    if "gpu" not in mexpr or "not gpu" in mexpr or not os.path.exists("/dev/kfd"):
+        return
+    if session.config.getoption("collectonly", False):
+        return
+    os.makedirs(os.path.dirname(DP_CHECK["log"]), exist_ok=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "4"
+    with open(DP_CHECK["log"], "w") as f:
+        DP_CHECK["proc"] = subprocess.Popen(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+             "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "tools", "check_dp_gpu.py")],
+            stdout=f, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    p = DP_CHECK["proc"]
+    if p is not None and p.poll() is None:
+        p.kill()
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}

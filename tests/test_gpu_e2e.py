@@ -241,7 +241,8 @@ def test_training_driver_validates_and_checkpoints_every_500_batches(dev, tmp_pa
     valid = [make_batch(170, 4, 300, review_net_only=True, max_sent_count=6, min_sent_count=5)]
     path = str(tmp_path / "best.pt")
     lines = []
-    opt = training(train, valid, model, cfg, path, logger=type("L", (), {"info": staticmethod(lines.append)}))
+    opt, saved = training(train, valid, model, cfg, path, logger=type("L", (), {"info": staticmethod(lines.append)}))
+    assert saved
     assert lines[0].startswith("Initial validation mse is")
     assert sum("batch   500" in ln for ln in lines) == 1                 # 2 epochs x 260 batches: one 500-batch mark
     assert sum(ln.startswith("Epoch") and "done" in ln for ln in lines) == 2
@@ -249,4 +250,125 @@ def test_training_driver_validates_and_checkpoints_every_500_batches(dev, tmp_pa
     assert os.path.exists(path)
     meta = load_checkpoint(path, model, opt, map_location=dev)            # the state at batch 500
     assert meta["batch_counter"] == 500 and meta["best_loss"] < 100
+    assert meta["epoch"] == 1 and meta["batch_in_epoch"] == 240          # 500 = 260 + 240
     assert abs(evaluate_mse(model, valid) - meta["best_loss"]) < 1e-6
+
+
+def test_driver_level_resume_is_exact(dev, tmp_path):
+    """`--resume` continues a run exactly: a shuffled DataLoader, a checkpoint taken in the middle of epoch
+    1, then a fresh process-equivalent (new model, new loader, new generator) resumed from it ends with the same bits as
+    the uninterrupted run - shuffle order, position in the epoch, Adam state and learning-rate schedule all restored."""
+    from torch.utils.data import DataLoader
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import training
+    P = make_param_state(181, 50, 300, 1, True, m_scale=0.05)
+    samples = [make_batch(190 + i, 2, 300, review_net_only=True, max_sent_count=6, min_sent_count=6, full_pad=True)
+               for i in range(10)]
+
+    def run(resume, path, epochs):
+        cfg = _cfg(review_net_only=True, train_epochs=epochs, learning_rate=1e-3, lr_decay=0.5)
+        Config_extra = dict(valid_every=7, resume=resume)
+        for k, v in Config_extra.items():
+            setattr(cfg, k, v)
+        torch.manual_seed(11)
+        m = UMPR(cfg, P["embedding.weight"].numpy())
+        m.load_state_dict(P)
+        m = m.to(dev)
+        g = torch.Generator().manual_seed(0)
+        train = DataLoader(samples, batch_size=None, shuffle=True, generator=g)   # each "sample" is a collated batch
+        lines = []
+        _, saved = training(train, [samples[0]], m, cfg, path, logger=type("L", (), {"info": staticmethod(lines.append)}))
+        return m, saved, lines
+
+    full, _, _ = run("", str(tmp_path / "full.pt"), 3)
+    # interrupted twin: stop after the checkpoint of batch 14 (epoch 1, 4 batches in) by training 2 epochs only ...
+    part, saved, lines = run("", str(tmp_path / "part.pt"), 2)
+    assert saved
+    from umpr_amd.checkpoint import load_checkpoint
+    meta = load_checkpoint(str(tmp_path / "part.pt"), part, map_location=dev)
+    assert meta["epoch"] >= 0 and "epoch_rng" in meta and "batch_in_epoch" in meta
+    # ... and resume from that checkpoint for the remaining epochs
+    res, _, rlines = run(str(tmp_path / "part.pt"), str(tmp_path / "res.pt"), 3)
+    assert any(ln.startswith("Resumed from") for ln in rlines)
+    for (k, a), (_, c) in zip(full.state_dict().items(), res.state_dict().items()):
+        assert torch.equal(a, c), k
+
+
+def test_two_rank_data_parallel_on_real_kernels():
+    """tools/check_dp_gpu.py (started by conftest before this process touched the GPU): two ranks share the box's one GPU
+    (gloo transport; RCCL refuses two ranks on one device), drive the full model through train_step's machinery with the
+    overlapped GradReducer and in-place VGG gradients; after two optimiser steps the data-parallel parameters equal a
+    single-process replay of both shards, and the two-rank evaluate_mse equals the shard-by-shard evaluation."""
+    from conftest import DP_CHECK
+    p = DP_CHECK["proc"]
+    assert p is not None, "the two-rank job was not started (pytest not run with -m gpu?)"
+    rc = p.wait(timeout=900)
+    out = open(DP_CHECK["log"]).read()
+    assert rc == 0, out[-3000:]
+    assert "data-parallel parameters equal the sequential replay" in out, out[-3000:]
+    assert "two-rank evaluate_mse" in out, out[-3000:]
+    assert "short last batch" in out, out[-3000:]
+
+
+def test_umpr_r_full_size_vs_oracle(dev):
+    """BASELINE.json configs[0] at its real size: UMPR-R, batch 32, S = L = 20 fully padded (640 sequences per GRU call),
+    GloVe-50d - the oracle finishes a step in well under a second, so this is direct parity, not a property."""
+    from oracle import umpr_ref as R
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_batch, make_param_state
+    P = make_param_state(211, 50, 5000, 1, True, m_scale=0.05)
+    batch = make_batch(212, 32, 5000, review_net_only=True, full_pad=True)
+    assert tuple(batch[0].shape) == (32, 20, 20)
+    model = UMPR(_cfg(review_net_only=True), P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    pred, loss = model(*batch)
+    loss.backward()
+    for k, p in P.items():
+        if k != "embedding.weight":
+            p.requires_grad_(True)
+    rp, rl = R.umpr_forward(P, batch, review_net_only=True, aten=True)
+    rl.backward()
+    assert float((pred.detach().cpu() - rp.detach()).abs().max()) < 1e-4
+    assert abs(float(loss) - float(rl)) < 1e-4
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            ref = P[k].grad
+            assert float((p.grad.cpu() - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-6, k
+
+
+def test_cfg4_full_size_forward_vs_oracle_and_backward_properties(dev):
+    """BASELINE.json configs[3] per GPU: 4 views x 32 samples = 128 images through UMPR.forward.  Forward: predictions and
+    loss against the oracle at full size (eval mode; ~10 s of CPU).  Backward (no CPU reference at this size): two runs
+    are bitwise identical, and scaling the loss by 2 scales every gradient by exactly 2 (every kernel is linear in the
+    upstream gradient and x2 is exact in fp32)."""
+    from oracle import umpr_ref as R
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_batch, make_param_state
+    V = 4
+    P = make_param_state(221, 50, 3000, V, False, m_scale=0.05)
+    batch = make_batch(222, 32, 3000, V, full_pad=True)
+    assert tuple(batch[6].shape) == (32, V, 1, 3, 224, 224)
+    model = UMPR(_cfg(views=["food", "inside", "outside", "drink"]), P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+
+    def grads(scale):
+        model.zero_grad(set_to_none=True)
+        pred, loss = model(*batch)
+        (loss * scale).backward()
+        return pred.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    p1, l1, g1 = grads(1.0)
+    p2, l2, g2 = grads(1.0)
+    p3, l3, g3 = grads(2.0)
+    assert torch.equal(p1, p2) and torch.equal(l1, l2)
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g1[k], g2[k]), f"{k}: two runs differ"
+        assert torch.equal(g3[k], 2 * g1[k]), f"{k}: gradient is not linear in the upstream gradient"
+    with torch.no_grad():
+        rp, rl = R.umpr_forward(P, batch, review_net_only=False, aten=True)
+    assert float((p1.cpu() - rp).abs().max()) < 1e-4, float((p1.cpu() - rp).abs().max())
+    assert abs(float(l1) - float(rl)) < 1e-4

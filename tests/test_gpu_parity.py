@@ -105,7 +105,12 @@ def test_gemm(L, dev, M, N, K, ta, tb):
                                           (2, 64, 96, 56), (3, 40, 200, 28), (5, 256, 256, 14), (1, 512, 512, 14),
                                           # channel counts off the 32 / 128 tile grid, odd batch sizes, one image
                                           (4, 33, 65, 28), (7, 100, 36, 14), (2, 129, 257, 14), (1, 32, 32, 56),
-                                          (3, 48, 160, 56)])
+                                          (3, 48, 160, 56),
+                                          # the PRODUCTION channel counts of VGG16 on their own map sizes:
+                                          # conv3x3_igemm_v2<64,256,224> / <128,128,112> (+ <128,64,112> tail), wgrad_v2<2,16>,
+                                          # and the Winograd forward / dgrad / wgrad kernels at 56 / 28
+                                          (1, 64, 64, 224), (1, 64, 128, 112), (1, 128, 128, 112), (1, 128, 256, 56),
+                                          (2, 256, 256, 56), (1, 256, 512, 28), (2, 512, 512, 28)])
 def test_conv3x3(L, dev, N, Cin, Cout, HW):
     g = torch.Generator().manual_seed(N + Cin + Cout + HW)
     x = torch.randn(N, Cin, HW, HW, generator=g)
@@ -408,29 +413,60 @@ def _build(gname, dev):
     return g, model, batch
 
 
-def _compare_golden(g, model, pred, loss):
+def _fp64_yardstick(gname, g):
+    """Gradients of the same fixture from an fp64 run of the oracle on the CPU (5 s): the truth both fp32 paths - the
+    reference's CPU run stored in the fixture and the HIP run - are measured against (VERDICT r1 #2)."""
+    from oracle import umpr_ref as R
+    from umpr_amd.synthetic import make_batch, make_param_state
+    B, V, ronly, pseed, bseed, full_pad, vocab = [int(v) for v in g["meta"]]
+    P = make_param_state(pseed, 50, vocab, V, bool(ronly), m_scale=float(g["m_scale"]))
+    batch = make_batch(bseed, B, vocab, V, int(g["photo_count"]) if "photo_count" in g else 1,
+                       review_net_only=bool(ronly), full_pad=bool(full_pad))
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    for k, p in P64.items():
+        if k != "embedding.weight":
+            p.requires_grad_(True)
+    b64 = tuple(t.double() if t.is_floating_point() else t for t in batch)
+    masks = [torch.from_numpy(g["drop_mask0"]).double(), torch.from_numpy(g["drop_mask1"]).double()] if "drop_mask0" in g else None
+    _, loss = R.umpr_forward(P64, b64, review_net_only=bool(ronly), aten=True, train=masks is not None, dropout_masks=masks)
+    loss.backward()
+    return {k: p.grad for k, p in P64.items() if k != "embedding.weight" and p.grad is not None}
+
+
+def _compare_golden(g, model, pred, loss, gname=None):
     check("pred", pred, g["prediction"], atol=1e-4)
     check("loss", loss, g["loss"], atol=1e-4)
+    has_vgg = any("vgg16" in k for k, _ in model.named_parameters())
+    g64 = _fp64_yardstick(gname, g) if (has_vgg and gname) else None
     for k, p in model.named_parameters():
-        early = ".features." in k  # every conv below a flipped ReLU / pool decision sits on the flip plateau
+        vggp = "vgg16" in k
         if "grad/" + k in g:
-            # Early VGG blocks: gradients are sums over up to n*224*224 cancelling terms; test_vgg16_small shows (against
-            # an fp64 run) that the reference's fp32 CPU path itself is ~7e-4 of the tensor max away from the truth
-            # there, and that the HIP path is at least as close - so two fp32 paths may differ by a few 1e-3.
-            # tools/relu_flip_experiment.py (fp64, CPU): 1e-6 relative noise on one activation map flips a ReLU / pool
-            # decision and moves every earlier layer's gradient by 1-3e-3 relative L2; 1e-7 noise moves them by 0.
-            vggp = "vgg16" in k
-            first = k.endswith("features.0.weight")  # sum of n*224*224 cancelling terms: the noisiest tensor
-            check("grad " + k, p.grad, g["grad/" + k], atol=1e-6, rel_to_max=1e-2 if (first or early) else 2e-3,
-                  max_bad_frac=1e-3 if vggp else 0.0, max_bad=2 if vggp else 0,
-                  rel_l2=1e-2 if vggp else None)
+            ref, got, stride = torch.from_numpy(g["grad/" + k]), p.grad.detach().cpu(), 1
         elif "gradstat/" + k in g:
             stride = int(g["gradstat/" + k][3])
-            check("gradsample " + k, p.grad.reshape(-1)[::stride], g["gradsample/" + k], atol=1e-7,
-                  rel_to_max=1e-2 if early else 2e-3, max_bad_frac=1e-3, max_bad=2, rel_l2=1e-2)
+            ref, got = torch.from_numpy(g["gradsample/" + k]), p.grad.detach().cpu().reshape(-1)[::stride]
             l2 = float(p.grad.double().pow(2).sum().sqrt())
             log(f"gradnorm {k}: got {l2:.6e} ref {g['gradstat/' + k][2]:.6e}")
             assert abs(l2 - g["gradstat/" + k][2]) <= 2e-3 * g["gradstat/" + k][2] + 1e-12, k
+        else:
+            continue
+        if not vggp:
+            check("grad " + k, got.reshape(ref.shape), ref, atol=1e-6, rel_to_max=2e-3)
+            continue
+        # VGG gradients: a 13-layer ReLU / max-pool network is not smooth - the first decision that lands on the other
+        # side between two fp32 summation orders moves every earlier layer's gradient by 1-3e-3 relative L2
+        # (tools/relu_flip_experiment.py; 1e-7 relative noise moves them by exactly 0).  So the yardstick is the fp64 run:
+        # the HIP gradient must be as close to it as the reference's own fp32 CPU gradient is (factor 3), or - when the
+        # two fp32 paths flipped in different layers - within the flip plateau (4e-3 relative L2).  Kernel accuracy
+        # proper is pinned per layer at the production shapes by test_conv3x3 (2e-5 / 1e-4 absolute).
+        t64 = g64[k].reshape(-1)[::stride] if stride > 1 else g64[k].reshape(-1)
+        e_gpu = float((got.reshape(-1).double() - t64).norm())
+        e_ref = float((ref.reshape(-1).double() - t64).norm())
+        scale = float(t64.norm()) + 1e-300
+        log(f"grad {k}: L2 |hip-f64|={e_gpu:.3e} |ref32-f64|={e_ref:.3e} |g|={scale:.3e} ratio={e_gpu / max(e_ref, 1e-300):.2f} rel={e_gpu / scale:.2e}")
+        assert not torch.isnan(got).any(), k
+        assert e_gpu <= 3.0 * e_ref or e_gpu / scale <= 4e-3, (k, e_gpu, e_ref, e_gpu / scale)
+        check("grad " + k, got.reshape(ref.shape), ref, atol=1e-6, rel_to_max=5e-3, max_bad_frac=1e-3, max_bad=2, rel_l2=6e-3)
 
 
 @pytest.mark.parametrize("name", ["umpr_r_B4", "umpr_r_B4_soft", "umpr_r_B3_fullpad"])
@@ -441,7 +477,7 @@ def test_umpr_r_golden(dev, name):
     pred, loss = model(*batch)
     loss.backward()
     torch.cuda.synchronize()
-    _compare_golden(g, model, pred, loss)
+    _compare_golden(g, model, pred, loss, name)
 
 
 @pytest.mark.parametrize("name", ["umpr_full_V1_B2", "umpr_full_V1_B2_randnM", "umpr_full_V4_B2", "umpr_full_V1_B2_drop",
@@ -457,7 +493,7 @@ def test_umpr_full_golden(dev, name):
     pred, loss = model(*batch)
     loss.backward()
     torch.cuda.synchronize()
-    _compare_golden(g, model, pred, loss)
+    _compare_golden(g, model, pred, loss, name)
 
 
 def test_adam_kernel(L, dev):

@@ -92,6 +92,78 @@ def test_shard_batch_matches_chunk():
                 assert torch.equal(parts[r][i], ref[r])
 
 
+def test_short_last_batch_shards():
+    """ceil-sized chunks leave trailing ranks EMPTY when the last batch is short; every rank must still have a
+    defined role.  Pins the chunk table, active_shards (= replicas DataParallel would use) and that the pieces tile B."""
+    from umpr_amd import parallel
+    sizes = lambda B, w: [hi - lo for lo, hi in (parallel.shard_bounds(B, r, w) for r in range(w))]
+    assert sizes(9, 8) == [2, 2, 2, 2, 1, 0, 0, 0]
+    assert sizes(17, 8) == [3, 3, 3, 3, 3, 2, 0, 0]
+    assert sizes(33, 8) == [5, 5, 5, 5, 5, 5, 3, 0]
+    assert sizes(3, 8) == [1, 1, 1, 0, 0, 0, 0, 0]
+    assert sizes(64, 8) == [8] * 8
+    for B in range(1, 70):
+        for w in (1, 2, 3, 4, 8):
+            sz = sizes(B, w)
+            assert sum(sz) == B and [len(c) for c in torch.chunk(torch.arange(B), w)] == [s for s in sz if s]
+            assert parallel.active_shards(B, w) == sum(1 for s in sz if s)
+    from umpr_amd.synthetic import make_batch
+    b = make_batch(3, 3, 100, 1, img_hw=8)
+    s = parallel.shard_with_count(b, 5, 8)
+    assert s.n_active == 3 and s[0].shape[0] == 0 and s[6].shape[0] == 0 and len(s) == 8
+
+
+def _empty_shard_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from umpr_amd import parallel
+    from umpr_amd.optim import FusedAdam
+    parallel.init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    model = _TinyInPlace()
+    opt = FusedAdam(model, 1e-3, 1e-3)
+    red = parallel.GradReducer(opt, n_buckets=2)
+    X = torch.randn(3, 6, generator=torch.Generator().manual_seed(7))   # global batch of 3 on 2 ranks: chunks [2, 1]
+    for B in (3, 1):                                                    # then a batch of 1: chunks [1, 0]
+        lo, hi = parallel.shard_bounds(B, rank, world)
+        n_active = parallel.active_shards(B, world)
+        for g in opt.groups:
+            g.g.fill_(99.0)                                             # stale gradients of the previous step
+        opt.zero_grad()
+        if hi > lo:
+            model(X[lo:hi]).pow(2).sum().backward()
+            assert red.fired
+        else:
+            red.skip_backward()                                         # same collective sequence, zero contribution
+        red.finish()
+        torch.manual_seed(0)
+        twin = _Tiny()
+        topt = FusedAdam(twin, 1e-3, 1e-3)
+        total = [torch.zeros_like(a) for a in topt.grad_arenas()]
+        for r in range(world):                                          # sequential replay of every non-empty chunk
+            l2, h2 = parallel.shard_bounds(B, r, world)
+            if h2 > l2:
+                topt.zero_grad()
+                twin(X[l2:h2]).pow(2).sum().backward()
+                total = [t + a for t, a in zip(total, topt.grad_arenas())]
+        for a, t in zip(opt.grad_arenas(), total):
+            assert torch.allclose(a, t, atol=1e-6), (B, rank, (a - t).abs().max())
+        assert n_active == (2 if B == 3 else 1)
+    if rank == 0:
+        torch.save({"ok": torch.tensor(1)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_empty_shard_rank_joins_the_collectives_gloo(tmp_path):
+    """B < world (and B % world != 0): the rank without samples skips backward, contributes zeros through the SAME
+    sequence of all-reduces (early bucket + rest) and ends with the same summed gradients as its peer."""
+    out = str(tmp_path / "empty.pt")
+    mp.spawn(_empty_shard_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert os.path.exists(out)
+
+
 class _JointClassifier(torch.autograd.Function):
     """Both linear layers in ONE backward node, like umpr_amd.model._VGGClassifier: all weight gradients are returned
     together, so autograd runs their AccumulateGrad nodes in an order the reducer must not rely on."""
@@ -245,7 +317,7 @@ def test_checkpoint_roundtrip(tmp_path):
     m2 = _Tiny()
     o2 = FusedAdam(m2, 1e-3, 1e-3, lr_decay=0.5)
     meta = load_checkpoint(path, m2, o2)
-    assert meta == {"epoch": 3, "batch_counter": 1500, "best_loss": 0.9}
+    assert {k: meta[k] for k in ("epoch", "batch_counter", "best_loss")} == {"epoch": 3, "batch_counter": 1500, "best_loss": 0.9}
     assert o2.step_count == 7 and abs(o2.lr - 5e-4) < 1e-12
     for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert n1 == n2 and torch.equal(p1, p2)

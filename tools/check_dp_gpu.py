@@ -36,28 +36,38 @@ def main():
     cfg = Config(argv=[])
     cfg.views = ["unknown"]
     P = make_param_state(201, 50, 600, 1, False, m_scale=0.05)
-    steps = [make_batch(210 + i, 4, 600, 1) for i in range(2)]
+    # two even batches, then a short "last batch" of 3 (chunks [2, 1]) and one of a single sample (chunks [1, 0]:
+    # rank 1 has nothing to do but must join the collectives - ADVICE r1)
+    steps = [make_batch(210 + i, b, 600, 1) for i, b in enumerate((4, 4, 3, 1))]
     model = build(P, cfg, dev).eval()       # eval: no dropout, the reference replay sees the same function
     opt = FusedAdam(model, 1e-3, 1e-3)
     red = parallel.GradReducer(opt)
     assert red.early is not None and len(model.visual_net.vgg16[0].grad_callbacks) == 1
     fired = []
     for b in steps:
-        mine = parallel.shard_batch(b, rank, world)
+        mine = parallel.shard_with_count(b, rank, world)
+        if mine[0].shape[0] == 0:
+            opt.zero_grad()
+            red.skip_backward()
+            fired.append(red.fired)
+            red.finish()
+            opt.step(grad_scale=1.0 / mine.n_active)
+            continue
         model.eval()
         pred, loss = model(*mine)
         opt.zero_grad()
         loss.mean().backward()
         fired.append(red.fired)
         red.finish()
-        opt.step(grad_scale=1.0 / world)
+        opt.step(grad_scale=1.0 / mine.n_active)
     assert all(fired), "the early bucket did not start during backward"
     if rank == 0:
         ref = build(P, cfg, dev).eval()
         ropt = FusedAdam(ref, 1e-3, 1e-3)
         for b in steps:
             total = None
-            for r in range(world):
+            n_active = parallel.active_shards(b[0].shape[0], world)
+            for r in range(n_active):
                 shard = parallel.shard_batch(b, r, world)
                 ropt.zero_grad()
                 ref(*shard)[1].mean().backward()
@@ -68,21 +78,22 @@ def main():
             for g in ropt.groups:
                 for p in g.direct:
                     p._umpr_fresh = False
-            ropt.step(grad_scale=1.0 / world)
+            ropt.step(grad_scale=1.0 / n_active)
         worst = 0.0
         for (k, a), (_, c) in zip(model.state_dict().items(), ref.state_dict().items()):
             d = float((a - c).abs().max())
             worst = max(worst, d / (float(c.abs().max()) + 1e-30))
             assert torch.allclose(a, c, rtol=1e-6, atol=1e-9), (k, d)
         print(f"data-parallel parameters equal the sequential replay (worst relative difference {worst:.2e})", flush=True)
+        print("short last batch (3 samples -> chunks [2,1]; 1 sample -> chunks [1,0], rank 1 idle but in every collective): ok", flush=True)
     # evaluation: every rank scores its shard, (sum of squared errors, count) are all-reduced (src/evaluate.py:6-14)
     from umpr_amd.train import evaluate_mse
-    mse = evaluate_mse(model, [parallel.shard_batch(b, rank, world) for b in steps])
+    mse = evaluate_mse(model, [parallel.shard_with_count(b, rank, world) for b in steps])
     if rank == 0:
         se, n = 0.0, 0
         with torch.no_grad():   # shard by shard: the reference's sentence permutation couples the samples of a batch
             for b in steps:     # (SURVEY.md header fact 1), so a shard's predictions are not the full batch's
-                for r in range(world):
+                for r in range(parallel.active_shards(b[0].shape[0], world)):
                     sh = parallel.shard_batch(b, r, world)
                     pred, _ = model(*sh)
                     se += float(((pred.cpu() - sh[-1]) ** 2).sum())

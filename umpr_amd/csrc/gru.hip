@@ -312,6 +312,9 @@ int umpr_gru_recurrent_fwd(const float* gx, const float* whh_f, const float* bhh
     return -2;
   }
   dim3 grid(cdiv(N, TS), 2);
+  // family 3 counts BYTES (HBM/latency-bound kernel): per token and both directions gx 384 floats read, out 128
+  // written, saved gates 2*4*64 written when training
+  UmprProfScope prof(UMPR_K_GRU, 4.0 * N * L * (384 + 128 + (saved ? 512 : 0)), s);
   gru_fwd_kernel<<<grid, 256, 0, s>>>(p);
   UMPR_LAUNCH_CHECK("gru_fwd");
   return 0;
@@ -331,6 +334,8 @@ int umpr_gru_bptt(const float* dout, const float* out, const float* saved, const
     return -2;
   }
   dim3 grid(cdiv(N, TS), 2);
+  // bytes per token: dout 128 + out 128 + saved 512 read, dgx 384 written
+  UmprProfScope prof(UMPR_K_GRU, 4.0 * N * L * (128 + 128 + 512 + 384), s);
   gru_bwd_kernel<<<grid, 256, 0, s>>>(p);
   UMPR_LAUNCH_CHECK("gru_bwd");
   return 0;

@@ -222,23 +222,38 @@ def get_image(path, resize=(224, 224)):
         return np.zeros([3] + list(resize))
 
 
-def batch_loader(batch_list, ignore_photos=False, photo_size=(224, 224), pad=0):
+def batch_loader(batch_list, ignore_photos=False, photo_size=(224, 224), pad=0, shard=None):
+    """src/dataset.py:146-182.  `shard=(rank, world)` (data parallel, not in the reference): the review tensors are padded
+    to the GLOBAL batch's common (max_count, max_len) exactly as the reference's single collate does before
+    DataParallel scatters them (main.py:82), but only this rank's contiguous chunk is kept - and only its photos are
+    decoded, so R ranks do 1/R of the JPEG work each instead of all of it.  A ninth element then carries the number
+    of ranks with a non-empty chunk (parallel.active_shards)."""
+    lo, hi = 0, len(batch_list)
+    if shard is not None:
+        from .parallel import active_shards, shard_bounds
+        lo, hi = shard_bounds(len(batch_list), *shard)
+    mine = batch_list[lo:hi]
     users = [s[0] for s in batch_list]
     items = [s[1] for s in batch_list]
     uis = [s[2] for s in batch_list]
-    ratings = [s[4] for s in batch_list]
+    ratings = [s[4] for s in mine]
     photos = []
-    if not ignore_photos:
-        paths = [p for s in batch_list for view in s[3] for p in view]
+    if not ignore_photos and mine:
+        paths = [p for s in mine for view in s[3] for p in view]
         with ThreadPoolExecutor() as pool:
             imgs = iter(list(pool.map(lambda x: get_image(x, photo_size), paths)))
-        photos = [[[next(imgs) for _ in view] for view in s[3]] for s in batch_list]
+        photos = [[[next(imgs) for _ in view] for view in s[3]] for s in mine]
     max_count = max(max(len(u), len(i)) for u, i in zip(users, items))
     max_len = max(max(max(len(s) for s in u), max(len(s) for s in i)) for u, i in zip(users, items))
     pu, lu = pad_reviews(users, max_count, max_len, pad)
     pi, li = pad_reviews(items, max_count, max_len, pad)
     pui, lui = pad_reviews(uis, pad=pad)
-    return (torch.LongTensor(pu), torch.LongTensor(pi), torch.LongTensor(pui), torch.LongTensor(lu),
-            torch.LongTensor(li), torch.LongTensor(lui),
-            torch.from_numpy(np.asarray(photos, dtype=np.float32)) if photos else torch.Tensor([]),
-            torch.Tensor(ratings))
+    long = lambda rows: torch.LongTensor(rows[lo:hi]) if hi > lo else torch.zeros((0,) + tuple(torch.LongTensor(rows[:1]).shape[1:]), dtype=torch.long)
+    out = (long(pu), long(pi), long(pui), long(lu), long(li), long(lui),
+           torch.from_numpy(np.asarray(photos, dtype=np.float32)) if photos else
+           (torch.Tensor([]) if ignore_photos or not batch_list else
+            torch.zeros((0, len(batch_list[0][3]), len(batch_list[0][3][0]), 3) + tuple(photo_size))),
+           torch.Tensor(ratings))
+    if shard is not None:
+        out = out + (torch.tensor(active_shards(len(batch_list), shard[1])),)
+    return out

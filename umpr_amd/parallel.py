@@ -43,12 +43,41 @@ def init_distributed(backend=None):
     return rank, local, world
 
 
-def shard_batch(batch, rank, world):
-    """Contiguous chunks along dim 0, as DataParallel's scatter does (torch.chunk semantics)."""
-    B = batch[0].shape[0]
+def shard_bounds(B, rank, world):
+    """[lo, hi) of rank's contiguous chunk of a batch of B along dim 0 - torch.chunk semantics, i.e. DataParallel's
+    scatter (main.py:82): chunks of ceil(B/world); when B is small the trailing ranks get NOTHING (lo == hi) and the
+    reference simply runs fewer replicas.  A rank with an empty shard still joins every collective (train_step,
+    evaluate_mse) with zero gradients / (0, 0) sums; the gradient scale is 1 / active_shards(B, world)."""
+    per = -(-B // world) if B > 0 else 0
+    lo = min(B, rank * per)
+    return lo, min(B, lo + per)
+
+
+def active_shards(B, world):
+    """Number of non-empty chunks torch.chunk(B, world) yields = replicas DataParallel would use for this batch."""
+    if B <= 0:
+        return 1
     per = -(-B // world)
-    sl = slice(rank * per, min(B, (rank + 1) * per))
-    return tuple(t[sl] if (t.dim() > 0 and t.shape[0] == B) else t for t in batch)
+    return -(-B // per)
+
+
+def shard_batch(batch, rank, world):
+    """Contiguous chunks along dim 0, as DataParallel's scatter does (torch.chunk semantics).  May be empty."""
+    B = batch[0].shape[0]
+    lo, hi = shard_bounds(B, rank, world)
+    return tuple(t[lo:hi] if (t.dim() > 0 and t.shape[0] == B) else t for t in batch)
+
+
+class Shard(tuple):
+    """A rank's chunk of a collated batch plus `n_active`, the number of ranks whose chunk of that batch is non-empty
+    (= the replicas the reference's DataParallel would have used; the gradient mean runs over those)."""
+    n_active = 1
+
+
+def shard_with_count(batch, rank, world):
+    s = Shard(shard_batch(batch, rank, world))
+    s.n_active = active_shards(batch[0].shape[0], world)
+    return s
 
 
 def allreduce_arenas(arenas, n_buckets=4):
@@ -112,6 +141,18 @@ class GradReducer:
         for chunk in torch.chunk(arena[lo:hi], self.n_buckets):
             self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
         self.fired = True
+
+    def skip_backward(self):
+        """This rank has an empty shard (fewer samples than ranks in the last batch): no backward runs here, so the
+        gradients are set to zero and the early bucket is launched by hand - every rank must issue the same sequence of
+        collectives."""
+        for a in self.opt.grad_arenas():
+            a.zero_()
+        for g in self.opt.groups:
+            for p in g.direct:
+                p._umpr_fresh = False
+        if self.early is not None and active() and self.hooks:
+            self._fire()
 
     def finish(self):
         if not active():
