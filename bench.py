@@ -205,7 +205,8 @@ class HostFeeder:
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # UMPR_BENCH_FORCE_SPAWN=1 rehearses the self-launch path with a single worker on a one-GPU box
+    if (args.gpus > 1 or os.environ.get("UMPR_BENCH_FORCE_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
         return spawn_workers(args)           # before anything here imports or touches the GPU runtime
     import torch
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when the first
