@@ -66,6 +66,12 @@ size_t umpr_coattention_fwd_ws_bytes(int B, int SL);
 int umpr_coattention_fwd(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
                          float* soft_i, float* atte_u, long ld_u, float* atte_i, long ld_i, float* colmax,
                          int32_t* argcol, float* rowmax, int32_t* argrow, float* ws, size_t ws_bytes, void* stream);
+/* The same with the score contraction tanh(T G_u^T) on bf16 MFMA (operands rounded to bf16, fp32 accumulation; tanh,
+ * max, argmax, softmax in fp32) - the "attention" half of BASELINE.json configs[4].  Same outputs / saved tensors, and
+ * umpr_coattention_bwd consumes them unchanged. */
+int umpr_coattention_fwd_bf16(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
+                              float* soft_i, float* atte_u, long ld_u, float* atte_i, long ld_i, float* colmax,
+                              int32_t* argcol, float* rowmax, int32_t* argrow, float* ws, size_t ws_bytes, void* stream);
 size_t umpr_coattention_bwd_ws_bytes(int B, int SL);
 int umpr_coattention_bwd(const float* Gu, const float* Gi, const float* M, const float* T, const float* soft_u,
                          const float* soft_i, const float* colmax, const int32_t* argcol, const float* rowmax,
@@ -162,6 +168,48 @@ int umpr_conv3x3_bwd_weight(const float* dy, const float* x, float* dw, float* d
 int umpr_maxpool2_fwd(const float* x, float* y, long planes, int H, int W, void* stream);
 int umpr_maxpool2_bwd_relu(const float* x, const float* dy, float* dx, long planes, int H, int W, void* stream);
 
+/* ---- bf16 mixed precision (BASELINE.json configs[4]: "MFMA bf16 conv + attention; MSE within 1e-3 of fp32") ---------
+ * Replaces the same torchvision VGG16 call site (model.py:204-207,217) with bf16 activations / gradients, fp32
+ * accumulation and fp32 master weights: v_mfma_f32_32x32x16_bf16 implicit GEMM.  Activations live in the library's
+ * CB8-PF layout (umpr_amd/csrc/bf16_conv.hip: channel blocks of 8, padded-flat pixels with zero borders); a tensor of
+ * N x C x H x W takes umpr_bf16_tensor_bytes(...) bytes and is produced / read back by the two converters.  Per-layer
+ * entry points (parity tests): channels must be multiples of 64 (32 for a reduction), maps 224/112/56/28/14 square.
+ * ws: umpr_conv3x3_bf16_ws_bytes(...) bytes of scratch (packed bf16 weights, or split-K slabs of the weight gradient). */
+size_t umpr_bf16_tensor_bytes(int N, int C, int H, int W);
+int umpr_bf16_from_nchw_f32(const float* x, void* y, int N, int C, int H, int W, void* stream);
+int umpr_bf16_to_nchw_f32(const void* x, float* y, int N, int C, int H, int W, void* stream);
+size_t umpr_conv3x3_bf16_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int umpr_conv3x3_bf16_fwd(const void* x, const float* w, const float* bias, void* y, int N, int Cin, int H, int W,
+                          int Cout, int relu, void* ws, size_t ws_bytes, void* stream);
+/* dx = conv_transpose(dy, w) [* (mask_src > 0)], mask_src in the same layout as dx */
+int umpr_conv3x3_bf16_bwd_data(const void* dy, const float* w, const void* mask_src /*or NULL*/, void* dx, int N,
+                               int Cin, int H, int W, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* dw [Cout][Cin][3][3], db [Cout] in fp32 (overwritten) */
+int umpr_conv3x3_bf16_bwd_weight(const void* dy, const void* x, float* dw, float* db, int N, int Cin, int H, int W,
+                                 int Cout, void* ws, size_t ws_bytes, void* stream);
+int umpr_maxpool2_bf16_fwd(const void* x, void* y, int N, int C, int H, int W, void* stream);
+int umpr_maxpool2_bf16_bwd_relu(const void* x, const void* dy, void* dx, int N, int C, int H, int W, void* stream);
+/* The convolutional stage of VGG16 in bf16.  images fp32 [n][3][224][224]; params / grads: the same 32-pointer fp32
+ * tables as umpr_vgg16_features_*; acts: umpr_vgg16_bf16_act_bytes(n) bytes kept for backward; pool5 / d_pool5: fp32
+ * [n][25088] in NCHW flatten order (what the classifier consumes / produces). */
+size_t umpr_vgg16_bf16_act_bytes(int n_img);
+size_t umpr_vgg16_bf16_fwd_ws_bytes(int n_img);
+size_t umpr_vgg16_bf16_bwd_ws_bytes(int n_img);
+int umpr_vgg16_bf16_features_fwd(const float* images, const float* const* params, int n_img, void* acts, float* pool5,
+                                 void* ws, size_t ws_bytes, void* stream);
+int umpr_vgg16_bf16_features_bwd(const float* images, const float* const* params, int n_img, const void* acts,
+                                 const float* d_pool5, float* const* grads, void* ws, size_t ws_bytes, void* stream);
+/* The classifier on a compact fp32 arena of umpr_vgg16_cls_arena_bytes(n): [pool5 n x 25088][fc1, fc2 ReLU outputs]
+ * [their dropout outputs] - for callers whose feature stage does not use the fp32 activation arena (the bf16 path).
+ * Workspaces as for umpr_vgg16_classifier_fwd / _bwd. */
+size_t umpr_vgg16_cls_arena_bytes(int n_img);
+int umpr_vgg16_classifier_fwd_compact(const float* const* params, int n_img, int train, int use_masks, uint64_t seed,
+                                      float* cls_arena, uint8_t* masks, float* out, float* ws, size_t ws_bytes,
+                                      void* stream);
+int umpr_vgg16_classifier_bwd_compact(const float* const* params, int n_img, int train, const float* cls_arena,
+                                      const uint8_t* masks, const float* d_out, float* const* grads, float* d_pool5,
+                                      float* ws, size_t ws_bytes, void* stream);
+
 /* ---- K11-K12: visual head + fusion + losses (model.py:218-228,267-277) ----------------------------------------
  * V = 0 selects the review_net_only branch (model.py:267-269).  loss [3] = (loss, loss_r, loss_v). */
 int umpr_head_fwd(const float* rr, const float* c_u, const float* c_i, const float* prefer_pos,
@@ -201,7 +249,8 @@ int umpr_debug_poison_lds(void* sink, void* stream);
  * 1 conv3x3 wgrad, 2 generic GEMM, 3 GRU, 4 the Winograd batched GEMM alone (nested inside families 0 and 5; its
  * work is the MFMA FLOPs executed, 1/2.25 of the direct-convolution FLOPs counted for the same launch), 5 the
  * family-0 kernels run as data gradient (these overlap with wgrad on the library's side stream), 6 the Winograd
- * weight-gradient GEMM alone (nested inside family 1, executed FLOPs).  read() synchronises the recorded events and returns totals since reset():
+ * weight-gradient GEMM alone (nested inside family 1, executed FLOPs), 3 the recurrent GRU kernels (work = bytes),
+ * 7 / 8 / 9 the bf16 convolution forward / data-gradient / weight-gradient kernels (FLOPs over the padded pixel grid).  read() synchronises the recorded events and returns totals since reset():
  * milliseconds, algorithmic FLOPs, launches. */
 int umpr_profile_enable(int on);
 int umpr_profile_reset(void);

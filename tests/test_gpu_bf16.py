@@ -1,0 +1,345 @@
+"""bf16 mixed-precision path (BASELINE.json configs[4]: "MFMA bf16 conv + attention; MSE within 1e-3 of fp32").
+
+Per-layer: the bf16 implicit-GEMM convolution (forward, data gradient, weight gradient) at the PRODUCTION VGG16 shapes
+against torch's fp32 F.conv2d.  Two references per case:
+  * "q": F.conv2d in fp32 on the bf16-ROUNDED inputs - isolates the kernel (products of bf16 values are exact in fp32, so
+    only the summation order and the final rounding to bf16 differ): tight elementwise bound;
+  * "f": F.conv2d on the unrounded fp32 inputs - the stated bf16 bound: relative L2 error <= 2^-7 (one bf16 rounding of
+    each operand, 2^-9 relative each, plus the output rounding; errors add in quadrature over K).
+End to end: eval MSE / predictions of the bf16 model against the committed fp32 golden fixtures (reference outputs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+LOG = os.path.join(ROOT, "gpurun_out", "parity_bf16.log")
+BF16_REL_L2 = 2.0 ** -7
+
+
+def log(msg):
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, "a") as f:
+        f.write(msg + "\n")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from umpr_amd._lib import lib
+    return lib()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.fixture(autouse=True)
+def poison_lds(L, dev):
+    sink = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.call("umpr_debug_poison_lds", sink, st())
+    yield
+
+
+def to_cb8(L, x, dev, poison=True):
+    """fp32 NCHW host tensor -> device CB8-PF bf16 tensor (bytes)."""
+    N, C, H, W = x.shape
+    nb = L.size("umpr_bf16_tensor_bytes", N, C, H, W)
+    y = torch.full((nb,), 0xFF if poison else 0, dtype=torch.uint8, device=dev)   # 0xFFFF bf16 = NaN: unwritten pads show
+    L.call("umpr_bf16_from_nchw_f32", x.to(dev).contiguous(), y, N, C, H, W, st())
+    return y
+
+
+def from_cb8(L, y, shape, dev):
+    N, C, H, W = shape
+    out = torch.full(shape, float("nan"), device=dev)
+    L.call("umpr_bf16_to_nchw_f32", y, out, N, C, H, W, st())
+    return out.cpu()
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def q(t):
+    return t.bfloat16().float()
+
+
+def test_layout_roundtrip_and_pads(L, dev):
+    """fp32 -> CB8-PF -> fp32 is the bf16 rounding of the input; every pad / guard pixel of the tensor is zero."""
+    g = torch.Generator().manual_seed(1)
+    for shape in [(2, 64, 14, 14), (3, 8, 28, 28), (1, 24, 56, 56)]:
+        x = torch.randn(shape, generator=g)
+        y = to_cb8(L, x, dev)
+        back = from_cb8(L, y, shape, dev)
+        assert torch.equal(back, q(x))
+        N, C, H, W = shape
+        planes = (C + 7) // 8
+        img = y.view(torch.bfloat16).view(planes, -1, 8).float().cpu()          # [plane][pixel incl. guards][8]
+        assert torch.isfinite(img).all()
+        total = float(img.abs().sum())
+        assert abs(total - float(q(x).abs().sum())) <= 1e-3 * total              # nothing but the real pixels is non-zero
+
+
+# the 12 bf16 conv layers of VGG16 (the first, 3 -> 64, runs the fp32 first-layer kernel) + batches that make tiles
+# straddle images / rows, + the 512-pixel tile of the 64-channel layers on every map width
+SHAPES = [(1, 64, 64, 224), (2, 64, 64, 224), (1, 64, 128, 112), (2, 128, 128, 112), (1, 128, 256, 56), (2, 256, 256, 56),
+          (1, 256, 512, 28), (3, 512, 512, 28), (5, 512, 512, 14), (3, 64, 64, 56), (2, 128, 64, 28), (7, 64, 128, 14)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,HW", SHAPES)
+def test_conv3x3_bf16(L, dev, N, Cin, Cout, HW):
+    g = torch.Generator().manual_seed(N + Cin + Cout + HW)
+    x = torch.randn(N, Cin, HW, HW, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    gy = torch.randn(N, Cout, HW, HW, generator=g)
+    # references
+    y_f = F.relu(F.conv2d(x, w, b, padding=1))
+    xq, wq = q(x).requires_grad_(True), q(w).requires_grad_(True)
+    y_q = F.relu(F.conv2d(xq, wq, b, padding=1))
+    gz_q = q(gy * (y_q > 0))                         # gradient w.r.t. the pre-activation, as the bf16 path stores it
+    pre = F.conv2d(xq, wq, b, padding=1)
+    pre.backward(gz_q)
+    xd = to_cb8(L, x, dev)
+    wsb = L.size("umpr_conv3x3_bf16_ws_bytes", N, Cin, Cout, HW, HW)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    nb = L.size("umpr_bf16_tensor_bytes", N, Cout, HW, HW)
+    yd = torch.full((nb,), 0xFF, dtype=torch.uint8, device=dev)
+    wd, bd = w.to(dev), b.to(dev)
+    L.call("umpr_conv3x3_bf16_fwd", xd, wd, bd, yd, N, Cin, HW, HW, Cout, 1, ws, wsb, st())
+    y = from_cb8(L, yd, (N, Cout, HW, HW), dev)
+    assert torch.isfinite(y).all()
+    eq, ef = rel_l2(y, y_q), rel_l2(y, y_f)
+    err = (y - y_q.detach()).abs()
+    tol = 2.0 ** -8 * y_q.detach().abs() + 1e-3
+    log(f"bf16 conv fwd {N},{Cin},{Cout},{HW}: relL2 vs q {eq:.2e} vs f32 {ef:.2e} max|err| {float(err.max()):.2e} bad {int((err > tol).sum())}")
+    assert int((err > tol).sum()) == 0 and ef <= BF16_REL_L2
+    # the zero pads of the output must really be zero (the next layer's taps read them): every element of the CB8-PF
+    # tensor that is not a real pixel
+    img = yd.view(torch.bfloat16).float()
+    assert torch.isfinite(img).all()
+    assert abs(float(img.abs().sum()) - float(y.abs().sum())) <= 2e-3 * float(y.abs().sum()) + 1e-3
+    # data gradient, plain and with the ReLU mask of the layer below fused
+    gzd = to_cb8(L, gz_q, dev)
+    nbx = L.size("umpr_bf16_tensor_bytes", N, Cin, HW, HW)
+    dxd = torch.full((nbx,), 0xFF, dtype=torch.uint8, device=dev)
+    L.call("umpr_conv3x3_bf16_bwd_data", gzd, wd, None, dxd, N, Cin, HW, HW, Cout, ws, wsb, st())
+    dx = from_cb8(L, dxd, (N, Cin, HW, HW), dev)
+    err = (dx - xq.grad).abs()
+    tol = 2.0 ** -8 * xq.grad.abs() + 1e-3 * float(xq.grad.abs().max())
+    log(f"bf16 conv dgrad {N},{Cin},{Cout},{HW}: relL2 {rel_l2(dx, xq.grad):.2e} max|err| {float(err.max()):.2e} bad {int((err > tol).sum())}")
+    assert int((err > tol).sum()) == 0
+    mask_src = torch.randn(N, Cin, HW, HW, generator=g)
+    md = to_cb8(L, mask_src, dev)
+    L.call("umpr_conv3x3_bf16_bwd_data", gzd, wd, md, dxd, N, Cin, HW, HW, Cout, ws, wsb, st())
+    dxm = from_cb8(L, dxd, (N, Cin, HW, HW), dev)
+    assert torch.equal(dxm, dx * (q(mask_src) > 0)), "masked data gradient differs from mask x plain"
+    # weight / bias gradient: fp32 outputs, bf16 products are exact in fp32 - only the summation order differs
+    dw = torch.full(w.shape, float("nan"), device=dev)
+    db = torch.full(b.shape, float("nan"), device=dev)
+    L.call("umpr_conv3x3_bf16_bwd_weight", gzd, xd, dw, db, N, Cin, HW, HW, Cout, ws, wsb, st())
+    dwc, dbc = dw.cpu(), db.cpu()
+    sw, sb = float(wq.grad.abs().max()), float(gz_q.sum((0, 2, 3)).abs().max())
+    ew, eb = float((dwc - wq.grad).abs().max()), float((dbc - gz_q.sum((0, 2, 3))).abs().max())
+    log(f"bf16 conv wgrad {N},{Cin},{Cout},{HW}: max|err| {ew:.2e} of {sw:.2e}; bias {eb:.2e} of {sb:.2e}")
+    assert ew <= 1e-4 * sw + 1e-6 and eb <= 1e-4 * sb + 1e-5
+
+
+def test_maxpool_bf16(L, dev):
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 3, 16, 28, 28
+    x = q(torch.relu(torch.randn(N, C, H, W, generator=g) + 0.3)).requires_grad_(True)
+    y_ref = F.max_pool2d(x, 2, 2)
+    gy = q(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(gy)
+    xd = to_cb8(L, x.detach(), dev)
+    yd = torch.full((L.size("umpr_bf16_tensor_bytes", N, C, H // 2, W // 2),), 0xFF, dtype=torch.uint8, device=dev)
+    L.call("umpr_maxpool2_bf16_fwd", xd, yd, N, C, H, W, st())
+    assert torch.equal(from_cb8(L, yd, (N, C, H // 2, W // 2), dev), y_ref.detach())
+    gyd = to_cb8(L, gy, dev)
+    gxd = torch.full((L.size("umpr_bf16_tensor_bytes", N, C, H, W),), 0xFF, dtype=torch.uint8, device=dev)
+    L.call("umpr_maxpool2_bf16_bwd_relu", xd, gyd, gxd, N, C, H, W, st())
+    gx = from_cb8(L, gxd, (N, C, H, W), dev)
+    # ties (several equal maxima in a window, likely among the ReLU zeros) route to the FIRST maximum on both sides only if
+    # torch does the same; zeros never receive gradient through the fused ReLU mask, so compare where x > 0
+    assert torch.equal(gx, x.grad * (x.detach() > 0))
+    assert torch.isfinite(gxd.view(torch.bfloat16).float()).all()
+
+
+@pytest.mark.parametrize("B,S,Lm,m_scale", [(3, 20, 20, 0.05), (2, 7, 9, 1.0)])
+def test_review_head_bf16_scores(L, dev, B, S, Lm, m_scale):
+    """Co-attention with the score contraction on bf16 MFMA against the fp32 kernel path: same argmax routing machinery,
+    outputs within the bf16 bound (scores carry 2^-9 relative operand rounding into tanh / max / softmax)."""
+    from umpr_amd.model import _ReviewHead
+    from umpr_amd.synthetic import make_param_state
+    P = make_param_state(11, 50, 500, 1, False, with_vgg=False, m_scale=m_scale)
+    g = torch.Generator().manual_seed(B * 100 + S)
+    gu = (torch.randn(B, S * Lm, 128, generator=g) * 0.5).to(dev)
+    gi = (torch.randn(B, S * Lm, 128, generator=g) * 0.5).to(dev)
+    pre = "review_net."
+    keys = [pre + "r_net.M", pre + "s_net_u.Ms", pre + "s_net_u.Ws", pre + "s_net_i.Ms", pre + "s_net_i.Ws",
+            pre + "linear_u.weight", pre + "linear_i.weight"]
+    gout = torch.randn(B, 128, generator=g).to(dev)
+    res = {}
+    for bf in (False, True):
+        a, b = gu.clone().requires_grad_(True), gi.clone().requires_grad_(True)
+        wd = [P[k].detach().to(dev).requires_grad_(True) for k in keys]
+        out = _ReviewHead.apply(a, b, S, Lm, *wd, bf)
+        out.backward(gout)
+        res[bf] = (out.detach().cpu(), a.grad.cpu(), wd[0].grad.cpu())
+    e_out = float((res[True][0] - res[False][0]).abs().max())
+    e_g = rel_l2(res[True][1], res[False][1])
+    e_m = rel_l2(res[True][2], res[False][2])
+    log(f"review head bf16 scores B{B} S{S} m{m_scale}: max|dout| {e_out:.2e} relL2 dGu {e_g:.2e} dM {e_m:.2e}")
+    assert torch.isfinite(res[True][0]).all() and e_out <= 3e-2
+    assert e_g <= 0.2 and (e_m <= 0.2 or float(res[False][2].norm()) < 1e-6)
+
+
+def _vgg_pair(dev, seed):
+    from umpr_amd.model import VGG16
+    torch.manual_seed(seed)
+    ref = VGG16().to(dev).eval()
+    low = VGG16(dtype="bf16").to(dev).eval()
+    low.load_state_dict(ref.state_dict())
+    return ref, low
+
+
+def test_vgg16_bf16_vs_fp32_path(dev):
+    """The whole VGG16 in bf16 against the fp32 HIP path (itself pinned to torch).  Forward: 13 bf16 layers, each adding
+    ~2e-3 relative rounding noise (inputs, weights, output) in quadrature -> ~7e-3 relative L2 at the 1000-d output.
+    Gradients: that forward noise flips the ReLU / max-pool decision of the ~0.5 % of units whose pre-activation sits
+    within it of zero (measured: classifier.3 already differs by 6e-2 with the classifier itself in fp32), and every layer
+    further down adds its own flips - an intrinsic property of bf16 activations, not of the kernels (those are pinned
+    elementwise by test_conv3x3_bf16).  So the bound is on direction: cosine >= 0.9 and relative L2 <= 0.5 for every
+    parameter, tightening towards the output."""
+    ref, low = _vgg_pair(dev, 3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(4, 3, 224, 224, generator=g).to(dev)
+    gout = torch.randn(4, 1000, generator=g).to(dev)
+    y0 = ref(x)
+    y1 = low(x)
+    e = rel_l2(y1.detach().cpu(), y0.detach().cpu())
+    log(f"vgg16 bf16 fwd: relL2 {e:.2e}")
+    assert torch.isfinite(y1).all() and e <= 2e-2
+    y0.backward(gout)
+    y1.backward(gout)
+    bad = {}
+    for (k, p0), (_, p1) in zip(ref.named_parameters(), low.named_parameters()):
+        assert torch.isfinite(p1.grad).all(), k
+        e = rel_l2(p1.grad.cpu(), p0.grad.cpu())
+        cos = float((p1.grad * p0.grad).sum() / (p1.grad.norm() * p0.grad.norm() + 1e-30))
+        log(f"vgg16 bf16 d{k}: relL2 {e:.2e} cosine {cos:.4f} |g| {float(p0.grad.norm()):.3e}")
+        if e > 0.5 or cos < 0.9 or (k.startswith("classifier.6") and e > 2e-2):
+            bad[k] = (e, cos)
+    assert not bad, bad
+
+
+def _bf16_model(cfg_views, P, dev, dtype, review_net_only=False):
+    from umpr_amd.config import Config
+    from umpr_amd.model import UMPR
+    Config.extend({"dtype": "fp32"})
+    cfg = Config(argv=[])
+    cfg.review_net_only = review_net_only
+    cfg.views = cfg_views
+    cfg.dtype = dtype
+    model = UMPR(cfg, P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    return model.to(dev).eval()
+
+
+@pytest.mark.parametrize("name", ["umpr_full_V1_B2", "umpr_full_V4_B2", "umpr_full_V2_P2_B2"])
+def test_umpr_bf16_predictions_vs_fp32_golden(dev, name):
+    """Per-sample predictions of the bf16 model (conv stack + attention scores in bf16) against the reference's own fp32
+    outputs in the golden fixtures: the stated bf16 bound is 3e-2 absolute per prediction (7e-3 relative noise at the VGG
+    output, see test_vgg16_bf16_vs_fp32_path).  These fixtures hold TWO samples of a random-initialised model whose
+    predictions are 3-5 away from the labels, so their MSE moves by 2 * |pred - label| * |dpred| ~ 1e-2: the MSE criterion
+    of configs[4] is a statement about an evaluation SET and is tested on one below."""
+    from umpr_amd.synthetic import make_batch, make_param_state
+    g = load_golden(name)
+    B, V, ronly, pseed, bseed, full_pad, vocab = [int(v) for v in g["meta"]]
+    P = make_param_state(pseed, 50, vocab, V, bool(ronly), m_scale=float(g["m_scale"]))
+    batch = make_batch(bseed, B, vocab, V, int(g["photo_count"]) if "photo_count" in g else 1,
+                       review_net_only=bool(ronly), full_pad=bool(full_pad))
+    model = _bf16_model(["v%d" % i for i in range(V)], P, dev, "bf16", bool(ronly))
+    with torch.no_grad():
+        pred, loss = model(*batch)
+    labels = batch[-1]
+    mse_bf16 = float(((pred.cpu() - labels) ** 2).mean())
+    mse_f32 = float(((torch.from_numpy(g["prediction"]) - labels) ** 2).mean())
+    dp = float((pred.cpu() - torch.from_numpy(g["prediction"])).abs().max())
+    log(f"{name} bf16: mse {mse_bf16:.6f} vs fp32 {mse_f32:.6f} (diff {abs(mse_bf16 - mse_f32):.2e}); max|dpred| {dp:.2e}; "
+        f"loss {float(loss):.6f} vs {float(g['loss']):.6f}")
+    assert dp <= 3e-2
+    assert abs(float(loss) - float(g["loss"])) <= 5e-2
+
+
+def test_bf16_eval_mse_within_1e3_of_fp32(dev):
+    """north_star for configs[4]: "MSE within 1e-3 of fp32".  evaluate_mse (src/evaluate.py:6-14) over an evaluation set of
+    1024 synthetic samples (16 batches of 64, the per-GPU batch of configs[4]) with the SAME weights in fp32 and in bf16
+    mixed precision.  The output bias is first calibrated so that the mean prediction equals the mean label - what the
+    first steps of training do - which puts the residuals at the scale of the reference's published test MSEs (1 - 2)
+    instead of the 3 - 5 of an uncalibrated random initialisation."""
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import evaluate_mse
+    P = make_param_state(401, 50, 2000, 1, False, m_scale=0.05)
+    batches = [make_batch(410 + i, 64, 2000, 1) for i in range(16)]
+    m32 = _bf16_model(["unknown"], P, dev, "fp32")
+    with torch.no_grad():
+        mean_pred = float(torch.cat([m32(*b)[0] for b in batches[:4]]).mean())
+    mean_label = float(torch.cat([b[-1] for b in batches]).mean())
+    P["linear_fusion.0.bias"] = P["linear_fusion.0.bias"] + (mean_label - mean_pred)
+    m32 = _bf16_model(["unknown"], P, dev, "fp32")
+    m16 = _bf16_model(["unknown"], P, dev, "bf16")
+    mse32 = evaluate_mse(m32, batches)
+    mse16 = evaluate_mse(m16, batches)
+    with torch.no_grad():
+        d = torch.cat([m16(*b)[0] - m32(*b)[0] for b in batches[:4]]).cpu()
+    log(f"bf16 eval set: MSE fp32 {mse32:.6f} bf16 {mse16:.6f} diff {abs(mse16 - mse32):.2e}; per-sample dpred mean "
+        f"{float(d.mean()):.2e} std {float(d.std()):.2e} max {float(d.abs().max()):.2e}")
+    assert abs(mse16 - mse32) <= 1e-3
+
+
+def test_bf16_training_step_runs_and_tracks_fp32(dev):
+    """Two optimiser steps of the full model in bf16 mixed precision next to the fp32 path from the same start: finite,
+    the losses agree to 1e-3 and the fp32 master weights move the same way (Adam's sign-like first steps make the
+    parameter deltas robust to bf16 gradient noise)."""
+    from umpr_amd.config import Config
+    from umpr_amd.model import UMPR
+    from umpr_amd.optim import FusedAdam
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import train_step
+    Config.extend({"dtype": "fp32"})
+    P = make_param_state(301, 50, 500, 1, False, m_scale=0.05)
+    batches = [make_batch(310 + i, 3, 500, 1) for i in range(2)]
+    out = {}
+    for dt in ("fp32", "bf16"):
+        cfg = Config(argv=[])
+        cfg.views = ["unknown"]
+        cfg.dtype = dt
+        torch.manual_seed(5)
+        m = UMPR(cfg, P["embedding.weight"].numpy())
+        m.load_state_dict(P)
+        m = m.to(dev)
+        opt = FusedAdam(m, 1e-4, 1e-3)
+        m.visual_net.vgg16[0].dropout_masks = torch.ones(2, 3, 4096, dtype=torch.uint8, device=dev)   # same (no) dropout
+        losses = [float(train_step(m, opt, b)[1]) for b in batches]
+        out[dt] = (losses, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    log(f"bf16 train losses {out['bf16'][0]} vs fp32 {out['fp32'][0]}")
+    for a, b in zip(out["bf16"][0], out["fp32"][0]):
+        assert np.isfinite(a) and abs(a - b) <= 1e-3 * max(1.0, abs(b)) + 1e-3
+    for k in ("visual_net.vgg16.0.features.28.weight", "visual_net.vgg16.0.features.5.weight", "review_net.r_net.M"):
+        d0 = out["fp32"][1][k] - P[k].to(dev)
+        d1 = out["bf16"][1][k] - P[k].to(dev)
+        cos = float((d0 * d1).sum() / (d0.norm() * d1.norm() + 1e-30))
+        log(f"bf16 train delta {k}: cosine {cos:.4f}")
+        assert cos > 0.8, (k, cos)

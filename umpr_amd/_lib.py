@@ -27,6 +27,7 @@ SIGNATURES = {
     "umpr_embed_gru_bidir_bwd": ("ppipppppiippppppppppppzp", "i"),
     "umpr_coattention_fwd_ws_bytes": ("ii", "z"),
     "umpr_coattention_fwd": ("pppiipppplplpppppzp", "i"),
+    "umpr_coattention_fwd_bf16": ("pppiipppplplpppppzp", "i"),
     "umpr_coattention_bwd_ws_bytes": ("ii", "z"),
     "umpr_coattention_bwd": ("ppppppppppplplppiipppipzp", "i"),
     "umpr_snet_fwd": ("ppppiiiippppplp", "i"),
@@ -61,6 +62,23 @@ SIGNATURES = {
     "umpr_conv3x3_bwd_weight": ("ppppiiiiipzp", "i"),
     "umpr_maxpool2_fwd": ("ppliip", "i"),
     "umpr_maxpool2_bwd_relu": ("pppliip", "i"),
+    "umpr_bf16_tensor_bytes": ("iiii", "z"),
+    "umpr_bf16_from_nchw_f32": ("ppiiiip", "i"),
+    "umpr_bf16_to_nchw_f32": ("ppiiiip", "i"),
+    "umpr_conv3x3_bf16_ws_bytes": ("iiiii", "z"),
+    "umpr_conv3x3_bf16_fwd": ("ppppiiiiiipzp", "i"),
+    "umpr_conv3x3_bf16_bwd_data": ("ppppiiiiipzp", "i"),
+    "umpr_conv3x3_bf16_bwd_weight": ("ppppiiiiipzp", "i"),
+    "umpr_maxpool2_bf16_fwd": ("ppiiiip", "i"),
+    "umpr_maxpool2_bf16_bwd_relu": ("pppiiiip", "i"),
+    "umpr_vgg16_bf16_act_bytes": ("i", "z"),
+    "umpr_vgg16_bf16_fwd_ws_bytes": ("i", "z"),
+    "umpr_vgg16_bf16_bwd_ws_bytes": ("i", "z"),
+    "umpr_vgg16_bf16_features_fwd": ("ppipppzp", "i"),
+    "umpr_vgg16_bf16_features_bwd": ("ppippppzp", "i"),
+    "umpr_vgg16_cls_arena_bytes": ("i", "z"),
+    "umpr_vgg16_classifier_fwd_compact": ("piiiuppppzp", "i"),
+    "umpr_vgg16_classifier_bwd_compact": ("piippppppzp", "i"),
     "umpr_head_fwd": ("pppppppppppppfiiipppppppp", "i"),
     "umpr_head_bwd": ("pppppppppppfiiippppppppppppppppppppp", "i"),
     "umpr_bce_head_fwd": ("plpppiipppzp", "i"),

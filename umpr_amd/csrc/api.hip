@@ -168,6 +168,12 @@ int umpr_coattention_fwd(const float* Gu, const float* Gi, const float* M, int B
   return umpr_coattn_fwd_impl(Gu, Gi, M, B, SL, T, soft_u, soft_i, atte_u, ld_u, atte_i, ld_i, colmax, argcol, rowmax,
                               argrow, ws, ws_bytes, S(stream));
 }
+int umpr_coattention_fwd_bf16(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
+                              float* soft_i, float* atte_u, long ld_u, float* atte_i, long ld_i, float* colmax,
+                              int32_t* argcol, float* rowmax, int32_t* argrow, float* ws, size_t ws_bytes, void* stream) {
+  return umpr_coattn_fwd_impl(Gu, Gi, M, B, SL, T, soft_u, soft_i, atte_u, ld_u, atte_i, ld_i, colmax, argcol, rowmax,
+                              argrow, ws, ws_bytes, S(stream), 1);
+}
 size_t umpr_coattention_bwd_ws_bytes(int B, int SL) { return umpr_coattn_bwd_ws_bytes(B, SL); }
 int umpr_coattention_bwd(const float* Gu, const float* Gi, const float* M, const float* T, const float* soft_u,
                          const float* soft_i, const float* colmax, const int32_t* argcol, const float* rowmax,
@@ -344,30 +350,58 @@ int umpr_vgg16_features_fwd(const float* images, const float* const* params, int
   return 0;
 }
 
-int umpr_vgg16_classifier_fwd(const float* const* params, int n, int train, int use_masks, uint64_t seed, float* acts,
-                              uint8_t* masks, float* out, float* ws, size_t ws_bytes, void* stream) {
-  UMPR_REQUIRE(n > 0 && params && acts && out, "vgg16_classifier_fwd: bad arguments");
-  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_fwd_ws_bytes(n), "vgg16_classifier_fwd: workspace too small");
-  const VggLayout L = vgg_layout(n);
-  hipStream_t s = S(stream);
+namespace {
+// classifier activations: pool5 input [n][25088], ReLU outputs of fc1 / fc2 and their dropout outputs ([n][4096] each)
+struct ClsActs { const float* pool5; float* fc[2]; float* drop[2]; };
+
+int classifier_fwd_impl(const float* const* params, int n, int train, int use_masks, uint64_t seed, const ClsActs& A,
+                        uint8_t* masks, float* out, float* ws, size_t ws_bytes, hipStream_t s) {
   // AdaptiveAvgPool2d(7) is the identity on the 7x7 map a 224x224 image produces
-  const float* x = acts + L.pool_off[4];
+  const float* x = A.pool5;
   for (int j = 0; j < 3; ++j) {
     UmprGemm g;
     g.A = x; g.lda = kFc[j][0]; g.B = params[26 + 2 * j]; g.ldb = kFc[j][0]; g.transB = true;
-    g.C = j < 2 ? acts + L.fc_off[j] : out; g.ldc = kFc[j][1]; g.M = n; g.N = kFc[j][1]; g.K = kFc[j][0];
+    g.C = j < 2 ? A.fc[j] : out; g.ldc = kFc[j][1]; g.M = n; g.N = kFc[j][1]; g.K = kFc[j][0];
     g.bias = params[27 + 2 * j]; g.bias_mode = 1; g.act = j < 2 ? UMPR_ACT_RELU : UMPR_ACT_NONE;
     g.split_k = 0; g.ws = ws; g.ws_bytes = ws_bytes;
     if (int rc = umpr_gemm(g, s)) return rc;
     x = g.C;
     if (j < 2 && (train || use_masks)) {
-      float* y = acts + L.drop_off[j];
+      float* y = A.drop[j];
       if (int rc = umpr_dropout_fwd_impl(x, y, masks + (size_t)j * n * 4096, (long)n * 4096, 0.5f,
                                          seed + 0x9E3779B97F4A7C15ULL * (j + 1), use_masks ? 0 : 1, s)) return rc;
       x = y;
     }
   }
   return 0;
+}
+ClsActs cls_acts_full(float* acts, int n) {
+  const VggLayout L = vgg_layout(n);
+  return ClsActs{acts + L.pool_off[4], {acts + L.fc_off[0], acts + L.fc_off[1]}, {acts + L.drop_off[0], acts + L.drop_off[1]}};
+}
+ClsActs cls_acts_compact(float* arena, int n) {
+  float* fc = arena + (size_t)n * 25088;
+  const size_t q = (size_t)n * 4096;
+  return ClsActs{arena, {fc, fc + q}, {fc + 2 * q, fc + 3 * q}};
+}
+}  // namespace
+
+int umpr_vgg16_classifier_fwd(const float* const* params, int n, int train, int use_masks, uint64_t seed, float* acts,
+                              uint8_t* masks, float* out, float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(n > 0 && params && acts && out, "vgg16_classifier_fwd: bad arguments");
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_fwd_ws_bytes(n), "vgg16_classifier_fwd: workspace too small");
+  return classifier_fwd_impl(params, n, train, use_masks, seed, cls_acts_full(acts, n), masks, out, ws, ws_bytes, S(stream));
+}
+
+size_t umpr_vgg16_cls_arena_bytes(int n_img) { return ((size_t)n_img * 25088 + (size_t)4 * n_img * 4096) * sizeof(float); }
+
+int umpr_vgg16_classifier_fwd_compact(const float* const* params, int n, int train, int use_masks, uint64_t seed,
+                                      float* cls_arena, uint8_t* masks, float* out, float* ws, size_t ws_bytes,
+                                      void* stream) {
+  UMPR_REQUIRE(n > 0 && params && cls_arena && out, "vgg16_classifier_fwd_compact: bad arguments");
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_fwd_ws_bytes(n), "vgg16_classifier_fwd_compact: workspace too small");
+  return classifier_fwd_impl(params, n, train, use_masks, seed, cls_acts_compact(cls_arena, n), masks, out, ws, ws_bytes,
+                             S(stream));
 }
 
 int umpr_vgg16_fwd(const float* images, const float* const* params, int n, int train, int use_masks, uint64_t seed,
@@ -382,12 +416,9 @@ size_t umpr_vgg16_classifier_bwd_ws_bytes(int n_img) {
 
 // d_pool5 [n][25088] receives the gradient w.r.t. the pooled feature map; grads: the 32-pointer array (only the six
 // classifier entries 26..31 are written).
-int umpr_vgg16_classifier_bwd(const float* const* params, int n, int train, const float* acts, const uint8_t* masks,
-                              const float* d_out, float* const* grads, float* d_pool5, float* ws, size_t ws_bytes,
-                              void* stream) {
-  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_classifier_bwd_ws_bytes(n), "vgg16_classifier_bwd: workspace too small");
-  const VggLayout L = vgg_layout(n);
-  hipStream_t s = S(stream);
+namespace {
+int classifier_bwd_impl(const float* const* params, int n, int train, const ClsActs& A, const uint8_t* masks,
+                        const float* d_out, float* const* grads, float* d_pool5, float* ws, size_t ws_bytes, hipStream_t s) {
   float* gA = ws;
   float* gB = ws + (size_t)n * 4096;
   float* scratch = gB + (size_t)n * 4096;
@@ -396,10 +427,10 @@ int umpr_vgg16_classifier_bwd(const float* const* params, int n, int train, cons
   float* cur = gA; float* oth = gB;
   for (int j = 2; j >= 0; --j) {
     const int fin = kFc[j][0], fout = kFc[j][1];
-    const float* xin = j == 0 ? acts + L.pool_off[4] : (train ? acts + L.drop_off[j - 1] : acts + L.fc_off[j - 1]);
+    const float* xin = j == 0 ? A.pool5 : (train ? A.drop[j - 1] : A.fc[j - 1]);
     if (j < 2) {
       // g is d(dropout output or relu output); fold dropout mask and ReLU into gz
-      if (int rc = umpr_dropout_bwd_impl(g, train ? masks + (size_t)j * n * 4096 : nullptr, acts + L.fc_off[j], cur,
+      if (int rc = umpr_dropout_bwd_impl(g, train ? masks + (size_t)j * n * 4096 : nullptr, A.fc[j], cur,
                                          (long)n * 4096, 0.5f, s)) return rc;
       g = cur; float* t = cur; cur = oth; oth = t;
     }
@@ -415,6 +446,23 @@ int umpr_vgg16_classifier_bwd(const float* const* params, int n, int train, cons
     g = d.C; float* t = cur; cur = oth; oth = t;
   }
   return 0;
+}
+}  // namespace
+
+int umpr_vgg16_classifier_bwd(const float* const* params, int n, int train, const float* acts, const uint8_t* masks,
+                              const float* d_out, float* const* grads, float* d_pool5, float* ws, size_t ws_bytes,
+                              void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_classifier_bwd_ws_bytes(n), "vgg16_classifier_bwd: workspace too small");
+  return classifier_bwd_impl(params, n, train, cls_acts_full(const_cast<float*>(acts), n), masks, d_out, grads, d_pool5,
+                             ws, ws_bytes, S(stream));
+}
+
+int umpr_vgg16_classifier_bwd_compact(const float* const* params, int n, int train, const float* cls_arena,
+                                      const uint8_t* masks, const float* d_out, float* const* grads, float* d_pool5,
+                                      float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_classifier_bwd_ws_bytes(n), "vgg16_classifier_bwd_compact: workspace too small");
+  return classifier_bwd_impl(params, n, train, cls_acts_compact(const_cast<float*>(cls_arena), n), masks, d_out, grads,
+                             d_pool5, ws, ws_bytes, S(stream));
 }
 
 size_t umpr_vgg16_features_bwd_ws_bytes(int n_img) {
@@ -518,6 +566,165 @@ int umpr_vgg16_bwd(const float* images, const float* const* params, int n, int t
   if (int rc = umpr_vgg16_classifier_bwd(params, n, train, acts, masks, d_out, grads, d_pool5, rest, rest_bytes, stream))
     return rc;
   return umpr_vgg16_features_bwd(images, params, n, acts, d_pool5, grads, rest, rest_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ bf16 path
+namespace {
+struct VggB16Layout {
+  UmprPF geo[5], pool_geo[5];          // map geometry of block b (224..14) and of its pooled output (112..7)
+  size_t conv_off[13], pool_off[5];    // byte offsets of the CB8-PF tensors in the activation arena
+  int conv_cin[13], conv_cout[13], conv_block[13];
+  size_t total;                        // bytes
+};
+VggB16Layout vgg_b16_layout(int n) {
+  VggB16Layout L;
+  size_t off = 0;
+  int cin = 3, hw = 224, ci = 0;
+  for (int b = 0; b < 5; ++b) {
+    L.geo[b] = umpr_pf(n, hw, hw);
+    for (int j = 0; j < kConvPerBlock[b]; ++j) {
+      L.conv_cin[ci] = cin; L.conv_cout[ci] = kBlockCh[b]; L.conv_block[ci] = b;
+      L.conv_off[ci] = off;
+      off += align_up(umpr_pf_bytes(L.geo[b], kBlockCh[b]), 1024);
+      cin = kBlockCh[b];
+      ++ci;
+    }
+    hw /= 2;
+    L.pool_geo[b] = umpr_pf(n, hw, hw);
+    L.pool_off[b] = off;
+    off += align_up(umpr_pf_bytes(L.pool_geo[b], kBlockCh[b]), 1024);
+  }
+  L.total = off;
+  return L;
+}
+size_t b16_pack_bytes() { return align_up(umpr_conv_bf16_pack_bytes(512, 512), 1024); }
+size_t b16_first_f32_bytes(int n) { return (size_t)n * 64 * 224 * 224 * sizeof(float); }
+size_t b16_wgrad_ws_bytes(int n) {
+  const VggB16Layout L = vgg_b16_layout(n);
+  size_t m = umpr_conv3x3_wgrad_ws_bytes(n, 3, 64, 224, 224);      // first layer: fp32 kernel
+  for (int i = 1; i < 13; ++i) {
+    const size_t b = umpr_wgrad_bf16_ws_bytes(L.geo[L.conv_block[i]], L.conv_cin[i], L.conv_cout[i]);
+    if (b > m) m = b;
+  }
+  return align_up(m, 1024);
+}
+inline char* BP(void* p) { return static_cast<char*>(p); }
+inline const char* CBP(const void* p) { return static_cast<const char*>(p); }
+}  // namespace
+
+size_t umpr_bf16_tensor_bytes(int N, int C, int H_, int W) { return umpr_pf_bytes(umpr_pf(N, H_, W), C); }
+int umpr_bf16_from_nchw_f32(const float* x, void* y, int N, int C, int H_, int W, void* stream) {
+  UMPR_REQUIRE(N > 0 && C > 0 && H_ > 0 && W > 0 && x && y, "bf16_from_nchw_f32: bad arguments");
+  return umpr_nchw_to_cb8(x, y, umpr_pf(N, H_, W), C, S(stream));
+}
+int umpr_bf16_to_nchw_f32(const void* x, float* y, int N, int C, int H_, int W, void* stream) {
+  UMPR_REQUIRE(N > 0 && C > 0 && H_ > 0 && W > 0 && x && y, "bf16_to_nchw_f32: bad arguments");
+  return umpr_cb8_to_nchw(x, y, umpr_pf(N, H_, W), C, S(stream));
+}
+size_t umpr_conv3x3_bf16_ws_bytes(int N, int Cin, int Cout, int H_, int W) {
+  const size_t a = umpr_conv_bf16_pack_bytes(Cin, Cout), b = umpr_wgrad_bf16_ws_bytes(umpr_pf(N, H_, W), Cin, Cout);
+  return align_up(a > b ? a : b, 1024);
+}
+int umpr_conv3x3_bf16_fwd(const void* x, const float* w, const float* bias, void* y, int N, int Cin, int H_, int W,
+                          int Cout, int relu, void* ws, size_t ws_bytes, void* stream) {
+  return umpr_conv_bf16_run(x, w, 0, bias, nullptr, y, umpr_pf(N, H_, W), Cin, Cout, relu, ws, ws_bytes, S(stream));
+}
+int umpr_conv3x3_bf16_bwd_data(const void* dy, const float* w, const void* mask_src, void* dx, int N, int Cin, int H_,
+                               int W, int Cout, void* ws, size_t ws_bytes, void* stream) {
+  return umpr_conv_bf16_run(dy, w, 1, nullptr, mask_src, dx, umpr_pf(N, H_, W), Cin, Cout, 0, ws, ws_bytes, S(stream));
+}
+int umpr_conv3x3_bf16_bwd_weight(const void* dy, const void* x, float* dw, float* db, int N, int Cin, int H_, int W,
+                                 int Cout, void* ws, size_t ws_bytes, void* stream) {
+  return umpr_wgrad_bf16_run(dy, x, dw, db, umpr_pf(N, H_, W), Cin, Cout, 0, static_cast<float*>(ws), ws_bytes, S(stream));
+}
+int umpr_maxpool2_bf16_fwd(const void* x, void* y, int N, int C, int H_, int W, void* stream) {
+  UMPR_REQUIRE((H_ % 2) == 0 && (W % 2) == 0 && (C % 8) == 0, "maxpool2_bf16: bad shape");
+  return umpr_maxpool2_bf16_fwd_run(x, y, umpr_pf(N, H_, W), umpr_pf(N, H_ / 2, W / 2), C, S(stream));
+}
+int umpr_maxpool2_bf16_bwd_relu(const void* x, const void* dy, void* dx, int N, int C, int H_, int W, void* stream) {
+  UMPR_REQUIRE((H_ % 2) == 0 && (W % 2) == 0 && (C % 8) == 0, "maxpool2_bf16: bad shape");
+  return umpr_maxpool2_bf16_bwd_run(x, dy, dx, umpr_pf(N, H_, W), umpr_pf(N, H_ / 2, W / 2), C, S(stream));
+}
+
+size_t umpr_vgg16_bf16_act_bytes(int n_img) { return vgg_b16_layout(n_img).total; }
+// forward scratch: [packed weights][fp32 output of the first conv]
+size_t umpr_vgg16_bf16_fwd_ws_bytes(int n_img) { return b16_pack_bytes() + b16_first_f32_bytes(n_img); }
+// backward scratch: [3 rotating gradient slots][packed weights][wgrad slabs][fp32 gradient of the first conv's output]
+size_t umpr_vgg16_bf16_bwd_ws_bytes(int n_img) {
+  const size_t slot = align_up(umpr_pf_bytes(umpr_pf(n_img, 224, 224), 64), 1024);
+  return 3 * slot + b16_pack_bytes() + b16_wgrad_ws_bytes(n_img) + b16_first_f32_bytes(n_img);
+}
+
+// Convolutional stage in bf16 (activations kept in `acts` for the backward pass); pool5 [n][25088] fp32 out, in the
+// NCHW flatten order the classifier's fc1 expects (torchvision: x.flatten(1) of [n][512][7][7]).
+int umpr_vgg16_bf16_features_fwd(const float* images, const float* const* params, int n, void* acts, float* pool5,
+                                 void* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(n > 0 && images && params && acts && pool5, "vgg16_bf16_features_fwd: bad arguments");
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_bf16_fwd_ws_bytes(n), "vgg16_bf16_features_fwd: workspace too small");
+  const VggB16Layout L = vgg_b16_layout(n);
+  hipStream_t s = S(stream);
+  void* wpack = ws;
+  float* f32 = reinterpret_cast<float*>(BP(ws) + b16_pack_bytes());
+  // first layer (3 input channels, K = 27): the fp32 first-layer kernel, then one conversion pass to CB8-PF bf16
+  if (int rc = umpr_conv3x3_run(images, params[0], 0, params[1], nullptr, f32, n, 3, 64, 224, 224, 1, nullptr, 0, s)) return rc;
+  if (int rc = umpr_nchw_to_cb8(f32, BP(acts) + L.conv_off[0], L.geo[0], 64, s)) return rc;
+  const void* x = BP(acts) + L.conv_off[0];
+  int ci = 1;
+  for (int b = 0; b < 5; ++b) {
+    for (int j = (b == 0 ? 1 : 0); j < kConvPerBlock[b]; ++j, ++ci) {
+      void* y = BP(acts) + L.conv_off[ci];
+      if (int rc = umpr_conv_bf16_run(x, params[2 * ci], 0, params[2 * ci + 1], nullptr, y, L.geo[b], L.conv_cin[ci],
+                                      L.conv_cout[ci], 1, wpack, b16_pack_bytes(), s)) return rc;
+      x = y;
+    }
+    void* y = BP(acts) + L.pool_off[b];
+    if (int rc = umpr_maxpool2_bf16_fwd_run(x, y, L.geo[b], L.pool_geo[b], kBlockCh[b], s)) return rc;
+    x = y;
+  }
+  return umpr_cb8_to_nchw(x, pool5, L.pool_geo[4], 512, s);
+}
+
+int umpr_vgg16_bf16_features_bwd(const float* images, const float* const* params, int n, const void* acts,
+                                 const float* d_pool5, float* const* grads, void* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_bf16_bwd_ws_bytes(n), "vgg16_bf16_features_bwd: workspace too small");
+  const VggB16Layout L = vgg_b16_layout(n);
+  hipStream_t s = S(stream);
+  const size_t slot = align_up(umpr_pf_bytes(umpr_pf(n, 224, 224), 64), 1024);
+  char* buf[3] = {BP(ws), BP(ws) + slot, BP(ws) + 2 * slot};
+  void* wpack = BP(ws) + 3 * slot;
+  float* slabs = reinterpret_cast<float*>(BP(ws) + 3 * slot + b16_pack_bytes());
+  const size_t slab_bytes = b16_wgrad_ws_bytes(n);
+  float* f32 = reinterpret_cast<float*>(BP(ws) + 3 * slot + b16_pack_bytes() + slab_bytes);
+  int nxt = 0;
+  auto claim = [&]() -> char* { char* p = buf[nxt]; nxt = (nxt + 1) % 3; return p; };
+  // gradient w.r.t. the pooled 7x7 map arrives in fp32 NCHW order from the classifier
+  char* g = claim();
+  if (int rc = umpr_nchw_to_cb8(d_pool5, g, L.pool_geo[4], 512, s)) return rc;
+  int ci = 12;
+  for (int b = 4; b >= 0; --b) {
+    // pool backward + ReLU mask of the conv output that fed the pool -> gradient w.r.t. that conv's pre-activation
+    char* cur = claim();
+    if (int rc = umpr_maxpool2_bf16_bwd_run(CBP(acts) + L.conv_off[ci], g, cur, L.geo[b], L.pool_geo[b], kBlockCh[b], s)) return rc;
+    g = cur;
+    for (int j = kConvPerBlock[b] - 1; j >= 0; --j, --ci) {
+      const int cin = L.conv_cin[ci], cout = L.conv_cout[ci];
+      if (ci == 0) {
+        // first layer: gradient back to fp32 NCHW, fp32 weight-gradient kernel on the fp32 images
+        if (int rc = umpr_cb8_to_nchw(g, f32, L.geo[0], 64, s)) return rc;
+        return umpr_conv3x3_wgrad(f32, images, grads[0], grads[1], n, 3, 64, 224, 224, 0, slabs, slab_bytes, s);
+      }
+      const void* xin = j == 0 ? CBP(acts) + L.pool_off[b - 1] : CBP(acts) + L.conv_off[ci - 1];
+      if (int rc = umpr_wgrad_bf16_run(g, xin, grads[2 * ci], grads[2 * ci + 1], L.geo[b], cin, cout, 0, slabs,
+                                       slab_bytes, s)) return rc;
+      // the input came straight from a conv+ReLU (j > 0): mask by it; from a pool (j == 0): the pool backward masks
+      const void* mask = j > 0 ? xin : nullptr;
+      cur = claim();
+      if (int rc = umpr_conv_bf16_run(g, params[2 * ci], 1, nullptr, mask, cur, L.geo[b], cin, cout, 0, wpack,
+                                      b16_pack_bytes(), s)) return rc;
+      g = cur;
+    }
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ head

@@ -1,0 +1,815 @@
+// bf16 mixed-precision VGG16 convolution stack for gfx950 (BASELINE.json configs[4]): v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation, activations and gradients in bf16, master weights / weight gradients in fp32.
+//
+// Activation layout "CB8-PF" (chosen for this hardware, not the reference's NCHW):
+//   * channel blocks of 8: tensor = [C/8 planes][plane stride ps][8] bf16 - one pixel of one plane is 16 B, the unit of
+//     ds_read_b128, of an MFMA k-half (8 consecutive k) and of one LDS-DMA lane;
+//   * padded-flat pixels: image n, row y, column x lives at pixel P = (n*(H+1) + y + 1) * (W+1) + x + 1.  Column 0 of
+//     every row and one row between (before, after) images are zero, so the 3x3 tap (dy,dx) of ANY pixel is pixel
+//     P + dy*(W+1) + dx - no boundary handling anywhere.  Kernels produce pixels [0, ptot) incl. the zero pads; a
+//     zeroed lead / tail guard around them keeps every tile's halo reads in bounds and finite.
+// With this layout an operand tile is a handful of contiguous runs per plane: it goes global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging registers), lands conflict-free for the fragment
+// reads ([plane][pixel] x 16 B: consecutive lanes = consecutive 16-B slots), the nine taps are an immediate offset on
+// the fragment address (zero VALU in the loop), and the epilogue's bf16 stores are whole 512-B runs per wave-instruction.
+//
+//   conv_bf16_kernel   forward and data gradient: D[cout][pixel] = sum_{tap,c} Wp[tap][cout][c] * X[pixel + off(tap)][c],
+//                      K-loop over (32-channel chunk, tap); weights for one step arrive 3 steps ahead in a 4-deep LDS ring
+//                      (counted vmcnt), the input patch of a chunk serves its 9 taps.  1-D tiles of consecutive flat
+//                      pixels on the narrow maps, 2-D tiles (smaller halo) on the 224 / 112 maps.
+//   wgrad_bf16_kernel  weight gradient: dW[tap][co][ci] = sum_P dY[P][co] * X[P + off(tap)][ci], K = pixels; both MFMA
+//                      operands are K-major in memory, so fragments come from ds_read_b64_tr_b16 (transposing LDS read);
+//                      9 accumulator tiles per wave, split-K over pixel segments into fp32 slabs + deterministic reduce.
+#include "umpr_common.h"
+#include "umpr_internal.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// ---- geometry ---------------------------------------------------------------------------------------------------
+UmprPF umpr_pf(int N, int H, int W) {
+  UmprPF g;
+  g.N = N; g.H = H; g.W = W; g.RW = W + 1;
+  g.rows = (long)N * (H + 1) + 1;
+  g.ptot = g.rows * g.RW;
+  g.lead = (long)align_up((size_t)g.RW + 2, 64);
+  // tail: the last tile may start just below ptot and reads a patch of up to 18 map rows (2-D tiles) or 512 + 2 RW
+  // pixels (1-D tiles) beyond its origin, rounded up to whole 64-pixel DMA pieces
+  g.tail = (long)align_up((size_t)18 * g.RW + 512 + 2 * g.RW + 128, 64);
+  g.ps = (long)align_up((size_t)(g.lead + g.ptot + g.tail), 64);
+  return g;
+}
+size_t umpr_pf_bytes(const UmprPF& g, int C) { return (size_t)((C + 7) / 8) * g.ps * 16; }
+
+namespace {
+
+// LDS-DMA: 64 lanes x 16 B; LDS destination = M0 (wave-uniform byte address) + lane * 16, per-lane global source.
+// Issued by inline asm so that hipcc neither waits vmcnt(0) behind it nor counts it; M0 is saved and restored.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+
+// pixel P of a map with row pitch RW and image pitch H+1 rows: a real pixel (not a zero pad)?
+template <int RW>
+__device__ __forceinline__ bool pf_real(long P, int H) {
+  const unsigned row = (unsigned)P / (unsigned)RW;     // P < 2^32 for every map that fits the GPU
+  const unsigned col = (unsigned)P - row * (unsigned)RW;
+  return col != 0 && (row % (unsigned)(H + 1)) != 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward / data gradient
+struct ConvB16Params {
+  const bf16_t* x; long xps;     // input: pixel 0 of plane 0, plane stride in pixels
+  const bf16_t* wp;              // packed weights [cout tile][chunk][tap][4 planes][BN][8]
+  const float* bias;             // [M] or null
+  const bf16_t* mask; long mps;  // dgrad: out *= (mask > 0), same layout as y; or null
+  bf16_t* y; long yps;
+  int C, M, H;                   // reduction channels (multiple of 32), output channels (multiple of BN), map height
+  long ptot;                     // pixels [0, ptot) are stored
+  long rows;                     // map rows incl. zero rows
+  int relu, nct;
+  long ntp;                      // pixel tiles
+};
+
+// W: map width.  TR > 0: 2-D tile of TR rows x TC real columns; TR == 0: 1-D tile of TC consecutive flat pixels.
+// BN output channels per workgroup; WP x WC waves (pixels x channels).
+template <int W, int TR, int TC, int BN, int WP, int WC>
+__global__ __launch_bounds__(64 * WP * WC) void conv_bf16_kernel(ConvB16Params p) {
+  constexpr int NW = WP * WC, NT = 64 * NW;
+  constexpr bool TWO_D = TR > 0;
+  constexpr int BM = TWO_D ? TR * TC : TC;
+  constexpr int RW = W + 1;
+  constexpr int LP = TC + 2;                      // 2-D patch row pitch (pixels)
+  constexpr int TS = TWO_D ? LP : RW;             // LDS pixels between the rows a tap's dy selects
+  constexpr int PATCH = TWO_D ? (TR + 2) * LP : BM + 2 * RW + 2;
+  constexpr int PPP = (PATCH + 63) / 64;          // DMA pieces per plane
+  constexpr int PPX = PPP * 64;                   // LDS pixels per plane
+  constexpr int PPC = 4 * PPP;                    // patch pieces per 32-channel chunk
+  constexpr int PPW = (PPC + NW - 1) / NW;        // ... per wave (surplus slots repeat a piece)
+  constexpr int WPS = BN / 16;                    // weight pieces per step (BN x 64 B)
+  constexpr int WPW = (WPS + NW - 1) / NW;
+  constexpr int D = 3, NB = D + 1;                // weights arrive D steps ahead in a ring of NB stages
+  constexpr int TPW = BM / WP / 32, TCW = BN / WC / 32;
+  constexpr int WB = BN * 32, PB = 4 * PPX * 8;   // elements per weight stage / patch stage
+  static_assert(BM % (32 * WP) == 0 && BN % (32 * WC) == 0 && (!TWO_D || (W % TC == 0 && TC % 16 == 0)), "tile shape");
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[NB * WB + 2 * PB];
+  bf16_t* const Wb = smem;
+  bf16_t* const Pb = smem + NB * WB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wpx = wave / WC, wco = wave % WC;
+  const int r = lane & 31, h = lane >> 5;
+
+  // XCD-aware order: workgroups b, b+8, ... share an XCD.  The weights of one output-channel tile (up to 2.4 MB) are what
+  // every pixel tile re-reads, so an XCD works on ONE channel tile where the tile count divides 8.
+  const int xcd = blockIdx.x & 7;
+  const long slot = blockIdx.x >> 3;
+  int ct; long pt;
+  if (p.nct <= 8 && (8 % p.nct) == 0) { const int g = 8 / p.nct; ct = xcd / g; pt = slot * g + (xcd % g); }
+  else { ct = (int)(slot % p.nct); pt = (slot / p.nct) * 8 + xcd; }
+  if (pt >= p.ntp) return;
+
+  long Q0; int ctile = 0;
+  if (TWO_D) {
+    constexpr int CT = W / TC;
+    const long band = pt / CT;
+    ctile = (int)(pt - band * CT);
+    Q0 = band * TR * RW + 1 + ctile * TC;
+  } else {
+    Q0 = pt * BM;
+  }
+
+  // ---- DMA plan of this wave
+  const int nchunks = p.C / 32;
+  const bf16_t* psrc[PPW]; unsigned pdst[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int q = (wave + NW * i) % PPC;
+    const int pl = q / PPP, pp = q - pl * PPP;
+    int u = pp * 64 + lane;
+    long gp;
+    if (TWO_D) {
+      if (u > PATCH - 1) u = PATCH - 1;
+      const int a = u / LP, b = u - a * LP;
+      gp = Q0 + (long)(a - 1) * RW + (b - 1);
+    } else {
+      gp = Q0 - RW - 1 + u;
+    }
+    psrc[i] = p.x + ((long)pl * p.xps + gp) * 8;
+    pdst[i] = lds_addr(Pb) + (unsigned)(pl * PPX + pp * 64) * 16u;
+  }
+  const bf16_t* wsrc[WPW]; unsigned wdst[WPW];
+  const bf16_t* wtile = p.wp + (long)ct * nchunks * 9 * WB;
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int q = (wave + NW * i) % WPS;
+    wsrc[i] = wtile + q * 512 + lane * 8;
+    wdst[i] = lds_addr(Wb) + (unsigned)q * 1024u;
+  }
+  const long chunk_stride = 4 * p.xps * 8;        // elements between 32-channel chunks of the input
+  const int S = nchunks * 9;
+  auto issue_w = [&](int s) {                     // stage of step s -> ring slot s % NB (steps past the end repeat the last)
+    const int sc = s < S ? s : S - 1;
+    const unsigned slot_off = (unsigned)(s % NB) * (WB * 2u);
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) glds16(wsrc[i] + (long)sc * WB, wdst[i] + slot_off);
+  };
+  auto issue_p = [&](int c) {                     // patch of chunk c -> buffer c & 1
+    const int cc = c < nchunks ? c : nchunks - 1;
+    const unsigned buf_off = (unsigned)(c & 1) * (PB * 2u);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(psrc[i] + cc * chunk_stride, pdst[i] + buf_off);
+  };
+
+  // ---- fragment addresses (bytes inside a stage)
+  unsigned pbo[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int k = wpx * (BM / WP) + j * 32 + r;
+    const int idx = TWO_D ? (k / TC + 1) * LP + (k % TC) + 1 : k + RW + 1;
+    pbo[j] = (unsigned)(h * PPX + idx) * 16u;
+  }
+  const unsigned wbo = (unsigned)(h * BN + wco * (BN / WC) + r) * 16u;
+
+  // accumulators start at the bias: D[cout][pixel], register x of a lane is cout (x&3) + 8*(x>>2) + 4*h of the tile
+  f32x16 acc[TCW][TPW];
+#pragma unroll
+  for (int i = 0; i < TCW; ++i) {
+    f32x16 b0;
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+      b0[x] = p.bias ? p.bias[ct * BN + wco * (BN / WC) + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[i][j] = b0;
+  }
+
+  issue_p(0);
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue_w(d);
+  wait_vm<(D - 1) * WPW>();
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const char* pb = reinterpret_cast<const char*>(Pb) + (c & 1) * (PB * 2);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int s = c * 9 + t;
+      issue_w(s + D);
+      if (t == 0) issue_p(c + 1);
+      const char* wb = reinterpret_cast<const char*>(Wb) + (s % NB) * (WB * 2);
+      constexpr int dummy = 0; (void)dummy;
+      const int toff = ((t / 3) - 1) * TS + (t % 3) - 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[TCW], b[TPW];
+#pragma unroll
+        for (int i = 0; i < TCW; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wb + wbo + (ks * 2 * BN + i * 32) * 16);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pb + pbo[j] + (ks * 2 * PPX + toff) * 16);
+#pragma unroll
+        for (int i = 0; i < TCW; ++i)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      // stage s+1 (and, from the fourth step of a chunk on, the next chunk's patch) must have landed; the younger DMAs
+      // (D-1 weight stages, plus the patch while it may still fly) stay in flight across the barrier
+      if (t < D) wait_vm<(D - 1) * WPW + PPW>(); else wait_vm<(D - 1) * WPW>();
+      __syncthreads();
+    }
+  }
+  wait_vm<0>();
+
+  // ---- epilogue: ReLU / mask, zero at pads, bf16, 8-B stores that pair up to whole 16-B pixels across the half-waves
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int k = wpx * (BM / WP) + j * 32 + r;
+    const long P = TWO_D ? Q0 + (long)(k / TC) * RW + (k % TC) : Q0 + k;
+    if (P >= p.ptot) continue;
+    const bool real = pf_real<RW>(P, p.H);
+#pragma unroll
+    for (int i = 0; i < TCW; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = ct * BN + wco * (BN / WC) + i * 32 + 8 * g + 4 * h;
+        const long o = ((long)(co >> 3) * p.yps + P) * 8 + (co & 7);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.mask) {
+          const bf16x4 m = *reinterpret_cast<const bf16x4*>(p.mask + ((long)(co >> 3) * p.mps + P) * 8 + (co & 7));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (float)m[e] > 0.f ? v[e] : 0.f;
+        }
+        bf16x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = (bf16_t)(real ? v[e] : 0.f);
+        *reinterpret_cast<bf16x4*>(p.y + o) = out;
+      }
+    }
+  }
+  if (TWO_D && ctile == 0) {   // column 0 (the zero pad) of this tile's rows: no tile computes it
+    const long row0 = Q0 / RW;
+    for (int e = tid; e < TR * (BN / 8); e += NT) {
+      const int i = e % TR, cb = e / TR;
+      const long P = (row0 + i) * RW;
+      if (P < p.ptot) {
+        bf16x8 z;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) z[q] = (bf16_t)0.f;
+        *reinterpret_cast<bf16x8*>(p.y + ((long)(ct * (BN / 8) + cb) * p.yps + P) * 8) = z;
+      }
+    }
+  }
+}
+
+// packed bf16 weights from the fp32 parameter w [Cout][Cin][3][3]:
+//   wp[ct][chunk][tap][pl][m][e],  output channel o = ct*BN + m, reduction channel c = chunk*32 + pl*8 + e
+//   forward  (transposed = 0): o = cout, c = cin, value w[o][c][tap]
+//   dgrad    (transposed = 1): o = cin,  c = cout, value w[c][o][8 - tap]
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int M, int C, int Cin,
+                                         int BN, int transposed) {
+  const long total = (long)M * C * 9;
+  const int nchunks = C / 32;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 7);
+    long q = idx >> 3;
+    const int m = (int)(q % BN); q /= BN;
+    const int pl = (int)(q & 3); q >>= 2;
+    const int tap = (int)(q % 9); q /= 9;
+    const int chunk = (int)(q % nchunks);
+    const int ct = (int)(q / nchunks);
+    const int o = ct * BN + m, c = chunk * 32 + pl * 8 + e;
+    const float v = transposed ? w[((long)c * Cin + o) * 9 + 8 - tap] : w[((long)o * Cin + c) * 9 + tap];
+    wp[idx] = (bf16_t)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient
+struct WgradB16Params {
+  const bf16_t* dy; long dps;    // [Cout/8][ps][8], zero at pads and in the guards
+  const bf16_t* x; long xps;     // [Cin/8][ps][8]
+  float* slab;                   // [splits][9][Cout][Cin]
+  int Cin, Cout;
+  long nseg;                     // pixel segments
+  int segs_per_split, splits, ntiles, ncit;
+};
+
+// segment: 1-D (TR == 0): TC consecutive flat pixels; 2-D: TR rows x TC real columns.  Workgroup tile = 32*WCO output
+// channels x 32*WCI input channels x 9 taps; KSW wave groups split the k-steps of every segment between them.
+template <int W, int TR, int TC, int WCO, int WCI, int KSW>
+__global__ __launch_bounds__(64 * WCO * WCI * KSW) void wgrad_bf16_kernel(WgradB16Params p) {
+  constexpr int NW = WCO * WCI * KSW, NT = 64 * NW;
+  constexpr bool TWO_D = TR > 0;
+  constexpr int KP = TWO_D ? TR * TC : TC;        // pixels per segment
+  constexpr int RW = W + 1;
+  constexpr int LP = TC + 2;
+  constexpr int TS = TWO_D ? LP : RW;
+  constexpr int PATCH = TWO_D ? (TR + 2) * LP : KP + 2 * RW + 2;
+  constexpr int PPP = (PATCH + 63) / 64;
+  constexpr int PPX = PPP * 64 + 4;               // +4 pixels: plane stride off the 256-B bank period (tr reads)
+  constexpr int KPX = KP + 4;
+  constexpr int GPL = 4 * WCO, XPL = 4 * WCI;     // dY planes / x planes of the tile
+  constexpr int GPC = GPL * (KP / 64), XPC = XPL * PPP;
+  constexpr int NPC = GPC + XPC;                  // DMA pieces per segment
+  constexpr int PCW = (NPC + NW - 1) / NW;
+  constexpr int GB = GPL * KPX * 8, XB = XPL * PPX * 8;   // elements per stage
+  constexpr int KSTEPS = KP / 16, KSL = KSTEPS / KSW;
+  static_assert(KP % 64 == 0 && KSTEPS % KSW == 0 && (!TWO_D || (W % TC == 0 && TC % 16 == 0)), "segment shape");
+  constexpr int RED = KSW > 1 ? WCO * WCI * 9 * 16 * 64 * 2 : 0;   // fp32 exchange of the wave groups, in bf16 units
+  constexpr int SMEM = 2 * (GB + XB) > RED ? 2 * (GB + XB) : RED;
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[SMEM];
+  bf16_t* const Gs = smem;                         // [2][GB]
+  bf16_t* const Xs = smem + 2 * GB;                // [2][XB]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ksw = wave / (WCO * WCI), wt = wave % (WCO * WCI);
+  const int wco = wt / WCI, wci = wt % WCI;
+  // workgroups of one split read the same pixels: keep them on one XCD (splits is a multiple of 8 or the tail idles)
+  const int xcd = blockIdx.x & 7;
+  const long qq = blockIdx.x >> 3;
+  const int tile = (int)(qq % p.ntiles);
+  const int split = (int)(qq / p.ntiles) * 8 + xcd;
+  if (split >= p.splits) return;
+  const int cot = tile / p.ncit, cit = tile % p.ncit;
+  const long sbeg = (long)split * p.segs_per_split;
+  const long send = min(p.nseg, sbeg + p.segs_per_split);
+
+  // ---- DMA plan: piece q of a segment; q < GPC: dY plane q / (KP/64), 64 pixels; else x plane, patch piece
+  const bf16_t* src0[PCW]; unsigned dst0[PCW]; int isx[PCW];
+#pragma unroll
+  for (int i = 0; i < PCW; ++i) {
+    const int q = (wave + NW * i) % NPC;
+    if (q < GPC) {
+      const int pl = q / (KP / 64), pp = q % (KP / 64);
+      const int k = pp * 64 + lane;
+      const long gp = TWO_D ? (long)(k / TC) * RW + (k % TC) : k;
+      src0[i] = p.dy + ((long)(cot * GPL + pl) * p.dps + gp) * 8;
+      dst0[i] = lds_addr(Gs) + (unsigned)(pl * KPX + pp * 64) * 16u;
+      isx[i] = 0;
+    } else {
+      const int q2 = q - GPC;
+      const int pl = q2 / PPP, pp = q2 % PPP;
+      int u = pp * 64 + lane;
+      long gp;
+      if (TWO_D) {
+        if (u > PATCH - 1) u = PATCH - 1;
+        const int a = u / LP, b = u - a * LP;
+        gp = (long)(a - 1) * RW + (b - 1);
+      } else {
+        gp = u - RW - 1;
+      }
+      src0[i] = p.x + ((long)(cit * XPL + pl) * p.xps + gp) * 8;
+      dst0[i] = lds_addr(Xs) + (unsigned)(pl * PPX + pp * 64) * 16u;
+      isx[i] = 1;
+    }
+  }
+  auto seg_origin = [&](long seg) -> long {
+    if (TWO_D) {
+      constexpr int CT = W / TC;
+      const long band = seg / CT;
+      return band * TR * RW + 1 + (seg - band * CT) * TC;
+    }
+    return seg * KP;
+  };
+  auto issue = [&](long seg, int buf) {
+    const long q0 = seg_origin(seg) * 8;
+#pragma unroll
+    for (int i = 0; i < PCW; ++i)
+      glds16(src0[i] + q0, dst0[i] + (unsigned)buf * (isx[i] ? XB * 2u : GB * 2u));
+  };
+
+  // ---- fragment addresses.  16-lane group g handles matrix rows/columns 16*(g&1).. and k-half g>>1; inside a group lane
+  // 4q+p supplies the address of k-row q, columns 4p..4p+3 (two planes x 8 channels per group).  Wave group ksw works
+  // on the k-steps kk*KSW + ksw: its 16-pixel offset (one patch row when a segment row holds a single k-step) is part
+  // of the lane base, so every k-step / tap offset below is a compile-time immediate.
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int kl = 8 * (g >> 1) + q4;                                  // + 4 for the second read of a k-step
+  const int kadv_g = ksw * 16;
+  const int kadv_x = ksw * ((TWO_D && TC == 16) ? LP : 16);
+  const unsigned abase = (unsigned)((wco * 4 + 2 * (g & 1) + (p4 >> 1)) * KPX + kl + kadv_g) * 16u + (p4 & 1) * 8u;
+  const unsigned bbase = (unsigned)((wci * 4 + 2 * (g & 1) + (p4 >> 1)) * PPX + kl + kadv_x) * 16u + (p4 & 1) * 8u;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[t][x] = 0.f;
+
+  if (sbeg < send) issue(sbeg, 0);
+  wait_vm<0>();
+  __syncthreads();
+  for (long seg = sbeg; seg < send; ++seg) {
+    const int cur = (int)(seg - sbeg) & 1;
+    issue(seg + 1 < send ? seg + 1 : seg, cur ^ 1);      // the last segment re-loads itself: uniform DMA count
+    const char* gs = reinterpret_cast<const char*>(Gs) + cur * (GB * 2) + abase;
+    const char* xs = reinterpret_cast<const char*>(Xs) + cur * (XB * 2) + bbase;
+#pragma unroll
+    for (int kk = 0; kk < KSL; ++kk) {
+      constexpr int dummy = 0; (void)dummy;
+      const int ko = kk * KSW * 16;                      // first pixel of wave group 0's k-step in the dY image
+      const int xo = TWO_D ? (ko / TC + 1) * LP + (ko % TC) + 1 : ko + RW + 1;   // ... and in the x patch (centre tap)
+      bf16x8 a;
+      {
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(gs + ko * 16));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(gs + (ko + 4) * 16));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = a0[e]; a[4 + e] = a1[e]; }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) - 1) * TS + (t % 3) - 1;
+        const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(xs + (xo + toff) * 16));
+        const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(xs + (xo + toff + 4) * 16));
+        bf16x8 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b[e] = b0[e]; b[4 + e] = b1[e]; }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    wait_vm<0>();
+    __syncthreads();
+  }
+
+  // ---- combine the KSW wave groups through LDS, then store the slab tile: D[co][ci], lanes run along ci
+  if (KSW > 1) {
+    float* red = reinterpret_cast<float*>(smem);       // [WCO*WCI][9][16][64] floats = 36 KB per wave
+    if (ksw == 1) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) red[((wt * 9 + t) * 16 + x) * 64 + lane] = acc[t][x];
+    }
+    __syncthreads();
+    if (ksw == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[t][x] += red[((wt * 9 + t) * 16 + x) * 64 + lane];
+    }
+  }
+  if (ksw == 0) {
+    const int r = lane & 31, h = lane >> 5;
+    const int ci = cit * 32 * WCI + wci * 32 + r;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int co = cot * 32 * WCO + wco * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+        p.slab[(((long)split * 9 + t) * p.Cout + co) * p.Cin + ci] = acc[t][x];
+      }
+  }
+}
+
+// bias gradient partial sums: bslab[chunk][co] = sum over the chunk's pixels of dY[P][co]
+__global__ __launch_bounds__(256) void bias_grad_bf16_kernel(const bf16_t* __restrict__ dy, long dps, long ptot,
+                                                            int Cout, int nchunk, float* __restrict__ bslab) {
+  const int cb = blockIdx.x, chunk = blockIdx.y;
+  const long per = (ptot + nchunk - 1) / nchunk;
+  const long beg = chunk * per, end = min(ptot, beg + per);
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  const bf16_t* base = dy + (long)cb * dps * 8;
+  for (long P = beg + threadIdx.x; P < end; P += 256) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + P * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+  }
+  __shared__ float red[4][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = wave_sum(s[e]);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x >> 6][e] = s[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) bslab[(long)chunk * Cout + cb * 8 + threadIdx.x] =
+      (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// layout conversion, pooling, guards
+// fp32 NCHW -> bf16 CB8-PF (zero pads written; channels past C are zero)
+__global__ void nchw_to_cb8_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long yps, int C, int H, int W,
+                                   long ptot) {
+  const int RW = W + 1;
+  const int cb = blockIdx.y;
+  for (long P = blockIdx.x * (long)blockDim.x + threadIdx.x; P < ptot; P += (long)gridDim.x * blockDim.x) {
+    const long row = P / RW; const int col = (int)(P - row * RW);
+    const int rr = (int)(row % (H + 1));
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+    if (col != 0 && rr != 0) {
+      const long n = row / (H + 1);
+      const long o = (n * C * H + (rr - 1)) * (long)W + (col - 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = cb * 8 + e;
+        if (c < C) v[e] = (bf16_t)x[o + (long)c * H * W];
+      }
+    }
+    *reinterpret_cast<bf16x8*>(y + ((long)cb * yps + P) * 8) = v;
+  }
+}
+
+// bf16 CB8-PF -> fp32 NCHW (real pixels only)
+__global__ void cb8_to_nchw_kernel(const bf16_t* __restrict__ x, long xps, float* __restrict__ y, int N, int C, int H,
+                                   int W) {
+  const int RW = W + 1;
+  const int cb = blockIdx.y;
+  const long total = (long)N * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W);
+    const long t = i / W;
+    const int yy = (int)(t % H);
+    const long n = t / H;
+    const long P = (n * (H + 1) + yy + 1) * RW + xx + 1;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)cb * xps + P) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cb * 8 + e;
+      if (c < C) y[((n * C + c) * H + yy) * (long)W + xx] = (float)v[e];
+    }
+  }
+}
+
+__global__ void zero_guards_kernel(bf16_t* __restrict__ base, long ps, long lead, long ptot) {
+  // base = start of plane 0 (not pixel 0): zero [0, lead) and [lead + ptot, ps) of every plane, 16 B per thread
+  const int pl = blockIdx.y;
+  const long tail0 = lead + ptot, n = lead + (ps - tail0);
+  uint4 z = make_uint4(0, 0, 0, 0);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long P = i < lead ? i : tail0 + (i - lead);
+    *reinterpret_cast<uint4*>(base + ((long)pl * ps + P) * 8) = z;
+  }
+}
+
+__device__ __forceinline__ bf16x8 max8(bf16x8 a, bf16x8 b) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (float)a[e] >= (float)b[e] ? a[e] : b[e];
+  return r;
+}
+
+// 2x2/2 max pooling on CB8-PF maps; writes every output pixel incl. the zero pads
+__global__ void maxpool2_bf16_fwd_kernel(const bf16_t* __restrict__ x, long xps, bf16_t* __restrict__ y, long yps, int H,
+                                         int W, long ptot_out) {
+  const int Ho = H / 2, Wo = W / 2, RWo = Wo + 1, RWi = W + 1;
+  const int cb = blockIdx.y;
+  for (long P = blockIdx.x * (long)blockDim.x + threadIdx.x; P < ptot_out; P += (long)gridDim.x * blockDim.x) {
+    const long row = P / RWo; const int col = (int)(P - row * RWo);
+    const int rr = (int)(row % (Ho + 1));
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+    if (col != 0 && rr != 0) {
+      const long n = row / (Ho + 1);
+      const long Pi = (n * (H + 1) + 2 * (rr - 1) + 1) * RWi + 2 * (col - 1) + 1;
+      const bf16_t* s = x + ((long)cb * xps + Pi) * 8;
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(s), b = *reinterpret_cast<const bf16x8*>(s + 8);
+      const bf16x8 c = *reinterpret_cast<const bf16x8*>(s + (long)RWi * 8), d = *reinterpret_cast<const bf16x8*>(s + (long)RWi * 8 + 8);
+      v = max8(max8(a, b), max8(c, d));
+    }
+    *reinterpret_cast<bf16x8*>(y + ((long)cb * yps + P) * 8) = v;
+  }
+}
+
+// gx = pool backward routed to the FIRST maximum of each window (order (0,0),(0,1),(1,0),(1,1), like the fp32 kernel),
+// zero where that maximum is not > 0 (ReLU of the activation that fed the pool); one thread per INPUT pixel, pads zero
+__global__ void maxpool2_bf16_bwd_relu_kernel(const bf16_t* __restrict__ x, long xps, const bf16_t* __restrict__ gy,
+                                              long gps, bf16_t* __restrict__ gx, long gxps, int H, int W, long ptot_in) {
+  const int Ho = H / 2, Wo = W / 2, RWo = Wo + 1, RWi = W + 1;
+  const int cb = blockIdx.y;
+  for (long P = blockIdx.x * (long)blockDim.x + threadIdx.x; P < ptot_in; P += (long)gridDim.x * blockDim.x) {
+    const long row = P / RWi; const int col = (int)(P - row * RWi);
+    const int rr = (int)(row % (H + 1));
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = (bf16_t)0.f;
+    if (col != 0 && rr != 0) {
+      const long n = row / (H + 1);
+      const int yy = rr - 1, xx = col - 1;
+      const int yo = yy >> 1, xo = xx >> 1, me = (yy & 1) * 2 + (xx & 1);
+      const long Pw = (n * (H + 1) + 2 * yo + 1) * RWi + 2 * xo + 1;
+      const bf16_t* s = x + ((long)cb * xps + Pw) * 8;
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(s), b = *reinterpret_cast<const bf16x8*>(s + 8);
+      const bf16x8 c = *reinterpret_cast<const bf16x8*>(s + (long)RWi * 8), d = *reinterpret_cast<const bf16x8*>(s + (long)RWi * 8 + 8);
+      const long Po = (n * (Ho + 1) + yo + 1) * RWo + xo + 1;
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(gy + ((long)cb * gps + Po) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int arg = 0; float m = (float)a[e];
+        if ((float)b[e] > m) { m = (float)b[e]; arg = 1; }
+        if ((float)c[e] > m) { m = (float)c[e]; arg = 2; }
+        if ((float)d[e] > m) { m = (float)d[e]; arg = 3; }
+        out[e] = (m > 0.f && arg == me) ? g[e] : (bf16_t)0.f;
+      }
+    }
+    *reinterpret_cast<bf16x8*>(gx + ((long)cb * gxps + P) * 8) = out;
+  }
+}
+
+inline int grid_for(long n, int cap) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  return (int)(b < 1 ? 1 : b);
+}
+
+template <int W, int TR, int TC, int BN, int WP, int WC>
+void launch_conv(ConvB16Params p, hipStream_t s) {
+  constexpr int BM = TR > 0 ? TR * TC : TC;
+  if (TR > 0) p.ntp = ((p.rows + TR - 1) / TR) * (W / TC);
+  else p.ntp = (p.ptot + BM - 1) / BM;
+  p.nct = p.M / BN;
+  long blocks;
+  if (p.nct <= 8 && (8 % p.nct) == 0) { const int g = 8 / p.nct; blocks = ((p.ntp + g - 1) / g) * 8; }
+  else blocks = ((p.ntp + 7) / 8) * 8 * p.nct;
+  conv_bf16_kernel<W, TR, TC, BN, WP, WC><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
+}
+
+// tile choice per map width and output-channel count (all 8 waves):
+//   M % 256 == 0 : 256 pixels x 256 channels, waves 2 x 4 (each 128 px x 64 ch)
+//   M % 128 == 0 : 256 x 128, waves 4 x 2 (64 x 64)
+//   else (64)    : 512 x 64, waves 8 x 1 (64 x 64)
+template <int W, int TR256, int TC256, int TR512, int TC512>
+int dispatch_conv_w(const ConvB16Params& p, hipStream_t s) {
+  if (p.M % 256 == 0) launch_conv<W, TR256, TC256, 256, 2, 4>(p, s);
+  else if (p.M % 128 == 0) launch_conv<W, TR256, TC256, 128, 4, 2>(p, s);
+  else if (p.M % 64 == 0) launch_conv<W, TR512, TC512, 64, 8, 1>(p, s);
+  else return -1;
+  return 0;
+}
+
+int conv_bn_for(int M) { return M % 256 == 0 ? 256 : (M % 128 == 0 ? 128 : 64); }
+
+constexpr int kWgradB16Wgs = 512;   // workgroups per launch the split-K factor aims at (2 rounds of 256 CUs)
+
+// segment / tile / split-K plan of a weight-gradient launch (shared by the workspace query and the launch)
+struct WgradPlan { bool big; long nseg; int ntiles, ncit, splits, segs_per_split; };
+WgradPlan wgrad_plan(const UmprPF& g, int Cin, int Cout) {
+  WgradPlan q;
+  q.big = (Cout % 128 == 0);                       // 128 co x 64 ci tiles; else 64 x 64 with two k-split wave groups
+  const int tco = q.big ? 128 : 64, tci = 64;
+  if (g.W == 224) q.nseg = ((g.rows + 3) / 4) * (224 / 32);        // 2-D segments 4 rows x 32 columns
+  else if (g.W == 112) q.nseg = ((g.rows + 7) / 8) * (112 / 16);   // 8 x 16
+  else q.nseg = (g.ptot + 127) / 128;                              // 128 consecutive flat pixels
+  q.ncit = Cin / tci;
+  q.ntiles = (Cout / tco) * q.ncit;
+  int splits = (kWgradB16Wgs + q.ntiles - 1) / q.ntiles;
+  splits = (splits + 7) / 8 * 8;
+  if (splits > q.nseg) splits = (int)q.nseg;
+  q.segs_per_split = (int)((q.nseg + splits - 1) / splits);
+  q.splits = (int)((q.nseg + q.segs_per_split - 1) / q.segs_per_split);
+  return q;
+}
+
+template <int W, int TR, int TC, int WCO, int WCI, int KSW>
+void launch_wgrad(WgradB16Params p, const WgradPlan& q, hipStream_t s) {
+  p.nseg = q.nseg; p.ncit = q.ncit; p.ntiles = q.ntiles; p.splits = q.splits; p.segs_per_split = q.segs_per_split;
+  const long blocks = (long)((q.splits + 7) / 8) * 8 * q.ntiles;
+  wgrad_bf16_kernel<W, TR, TC, WCO, WCI, KSW><<<dim3((unsigned)blocks), 64 * WCO * WCI * KSW, 0, s>>>(p);
+}
+
+}  // namespace
+
+// ---- internal host entry points ----------------------------------------------------------------------------------
+size_t umpr_conv_bf16_pack_bytes(int Cin, int Cout) { return (size_t)Cin * Cout * 9 * sizeof(bf16_t) + 1024; }
+
+// forward (transposed = 0): y[M = Cout] = relu?(conv(x[C = Cin]) + bias);  dgrad (transposed = 1): y[M = Cin] =
+// conv^T(x[C = Cout]) * [mask > 0].  x, y, mask: pointers to the START of plane 0 (incl. the lead guard) of CB8-PF
+// tensors of geometry g.  wpack: scratch of umpr_conv_bf16_pack_bytes.  The output's guards are zeroed here.
+int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const float* bias, const void* mask, void* y,
+                       const UmprPF& g, int Cin, int Cout, int relu, void* wpack, size_t wpack_bytes, hipStream_t s) {
+  const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
+  UMPR_REQUIRE(C % 32 == 0 && M % 64 == 0, "conv_bf16: channels (%d -> %d) must be multiples of 32 / 64", C, M);
+  UMPR_REQUIRE(g.H == g.W && (g.W == 224 || g.W == 112 || g.W == 56 || g.W == 28 || g.W == 14),
+               "conv_bf16: map %dx%d is not a VGG16 map size", g.H, g.W);
+  UMPR_REQUIRE(wpack_bytes >= umpr_conv_bf16_pack_bytes(Cin, Cout), "conv_bf16: weight scratch too small");
+  const int BN = conv_bn_for(M);
+  bf16_t* wp = static_cast<bf16_t*>(wpack);
+  pack_weights_bf16_kernel<<<grid_for((long)M * C * 9, 2048), 256, 0, s>>>(w, wp, M, C, Cin, BN, transposed);
+  UMPR_LAUNCH_CHECK("pack_weights_bf16");
+  bf16_t* y0 = static_cast<bf16_t*>(y);
+  zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), M / 8), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);
+  UMPR_LAUNCH_CHECK("zero_guards");
+  ConvB16Params p;
+  p.x = static_cast<const bf16_t*>(x) + g.lead * 8; p.xps = g.ps;
+  p.wp = wp; p.bias = bias;
+  p.mask = mask ? static_cast<const bf16_t*>(mask) + g.lead * 8 : nullptr; p.mps = g.ps;
+  p.y = y0 + g.lead * 8; p.yps = g.ps;
+  p.C = C; p.M = M; p.H = g.H; p.ptot = g.ptot; p.rows = g.rows; p.relu = relu; p.nct = 0; p.ntp = 0;
+  UmprProfScope prof(transposed ? UMPR_K_B16_DGRAD : UMPR_K_B16_FWD, 2.0 * (double)g.ptot * M * C * 9, s);
+  int rc;
+  switch (g.W) {
+    case 224: rc = dispatch_conv_w<224, 8, 32, 16, 32>(p, s); break;
+    case 112: rc = dispatch_conv_w<112, 16, 16, 32, 16>(p, s); break;
+    case 56: rc = dispatch_conv_w<56, 0, 256, 0, 512>(p, s); break;
+    case 28: rc = dispatch_conv_w<28, 0, 256, 0, 512>(p, s); break;
+    default: rc = dispatch_conv_w<14, 0, 256, 0, 512>(p, s); break;
+  }
+  UMPR_REQUIRE(rc == 0, "conv_bf16: unsupported channel count %d", M);
+  UMPR_LAUNCH_CHECK("conv_bf16");
+  return 0;
+}
+
+size_t umpr_wgrad_bf16_ws_bytes(const UmprPF& g, int Cin, int Cout) {
+  const WgradPlan q = wgrad_plan(g, Cin, Cout);
+  return (size_t)q.splits * ((size_t)9 * Cout * Cin + Cout) * sizeof(float) + 1024;
+}
+
+// dw [Cout][Cin][3][3], db [Cout] (fp32, overwritten or accumulated) from dy, x in CB8-PF (start-of-plane pointers)
+int umpr_wgrad_bf16_run(const void* dy, const void* x, float* dw, float* db, const UmprPF& g, int Cin, int Cout,
+                        int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "wgrad_bf16: channels (%d, %d) must be multiples of 64", Cin, Cout);
+  UMPR_REQUIRE(g.H == g.W && (g.W == 224 || g.W == 112 || g.W == 56 || g.W == 28 || g.W == 14),
+               "wgrad_bf16: map %dx%d is not a VGG16 map size", g.H, g.W);
+  UMPR_REQUIRE(ws_bytes >= umpr_wgrad_bf16_ws_bytes(g, Cin, Cout), "wgrad_bf16: workspace too small");
+  WgradB16Params p;
+  p.dy = static_cast<const bf16_t*>(dy) + g.lead * 8; p.dps = g.ps;
+  p.x = static_cast<const bf16_t*>(x) + g.lead * 8; p.xps = g.ps;
+  p.slab = ws; p.Cin = Cin; p.Cout = Cout;
+  const WgradPlan q = wgrad_plan(g, Cin, Cout);
+  {
+    UmprProfScope prof(UMPR_K_B16_WGRAD, 2.0 * (double)g.ptot * Cout * Cin * 9, s);
+    if (q.big) {
+      switch (g.W) {
+        case 224: launch_wgrad<224, 4, 32, 4, 2, 1>(p, q, s); break;
+        case 112: launch_wgrad<112, 8, 16, 4, 2, 1>(p, q, s); break;
+        case 56: launch_wgrad<56, 0, 128, 4, 2, 1>(p, q, s); break;
+        case 28: launch_wgrad<28, 0, 128, 4, 2, 1>(p, q, s); break;
+        default: launch_wgrad<14, 0, 128, 4, 2, 1>(p, q, s); break;
+      }
+    } else {
+      switch (g.W) {
+        case 224: launch_wgrad<224, 4, 32, 2, 2, 2>(p, q, s); break;
+        case 112: launch_wgrad<112, 8, 16, 2, 2, 2>(p, q, s); break;
+        case 56: launch_wgrad<56, 0, 128, 2, 2, 2>(p, q, s); break;
+        case 28: launch_wgrad<28, 0, 128, 2, 2, 2>(p, q, s); break;
+        default: launch_wgrad<14, 0, 128, 2, 2, 2>(p, q, s); break;
+      }
+    }
+  }
+  UMPR_LAUNCH_CHECK("wgrad_bf16");
+  const int splits = q.splits;
+  float* bslab = nullptr;
+  if (db) {
+    bslab = ws + (size_t)splits * 9 * Cout * Cin;
+    bias_grad_bf16_kernel<<<dim3(Cout / 8, splits), 256, 0, s>>>(p.dy, g.ps, g.ptot, Cout, splits, bslab);
+    UMPR_LAUNCH_CHECK("bias_grad_bf16");
+  }
+  return umpr_wgrad_reduce(ws, bslab, splits, Cout, Cin, dw, db, accumulate, s);
+}
+
+int umpr_nchw_to_cb8(const float* x, void* y, const UmprPF& g, int C, hipStream_t s) {
+  bf16_t* y0 = static_cast<bf16_t*>(y);
+  const int planes = (C + 7) / 8;
+  zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), planes), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);
+  nchw_to_cb8_kernel<<<dim3(grid_for(g.ptot, 4096), planes), 256, 0, s>>>(x, y0 + g.lead * 8, g.ps, C, g.H, g.W, g.ptot);
+  UMPR_LAUNCH_CHECK("nchw_to_cb8");
+  return 0;
+}
+
+int umpr_cb8_to_nchw(const void* x, float* y, const UmprPF& g, int C, hipStream_t s) {
+  const int planes = (C + 7) / 8;
+  cb8_to_nchw_kernel<<<dim3(grid_for((long)g.N * g.H * g.W, 4096), planes), 256, 0, s>>>(
+      static_cast<const bf16_t*>(x) + g.lead * 8, g.ps, y, g.N, C, g.H, g.W);
+  UMPR_LAUNCH_CHECK("cb8_to_nchw");
+  return 0;
+}
+
+int umpr_maxpool2_bf16_fwd_run(const void* x, void* y, const UmprPF& gi, const UmprPF& go, int C, hipStream_t s) {
+  bf16_t* y0 = static_cast<bf16_t*>(y);
+  zero_guards_kernel<<<dim3(grid_for(go.ps - go.ptot, 64), C / 8), 256, 0, s>>>(y0, go.ps, go.lead, go.ptot);
+  maxpool2_bf16_fwd_kernel<<<dim3(grid_for(go.ptot, 4096), C / 8), 256, 0, s>>>(
+      static_cast<const bf16_t*>(x) + gi.lead * 8, gi.ps, y0 + go.lead * 8, go.ps, gi.H, gi.W, go.ptot);
+  UMPR_LAUNCH_CHECK("maxpool2_bf16_fwd");
+  return 0;
+}
+
+int umpr_maxpool2_bf16_bwd_run(const void* x, const void* gy, void* gx, const UmprPF& gi, const UmprPF& go, int C,
+                               hipStream_t s) {
+  bf16_t* g0 = static_cast<bf16_t*>(gx);
+  zero_guards_kernel<<<dim3(grid_for(gi.ps - gi.ptot, 64), C / 8), 256, 0, s>>>(g0, gi.ps, gi.lead, gi.ptot);
+  maxpool2_bf16_bwd_relu_kernel<<<dim3(grid_for(gi.ptot, 4096), C / 8), 256, 0, s>>>(
+      static_cast<const bf16_t*>(x) + gi.lead * 8, gi.ps, static_cast<const bf16_t*>(gy) + go.lead * 8, go.ps,
+      g0 + gi.lead * 8, gi.ps, gi.H, gi.W, gi.ptot);
+  UMPR_LAUNCH_CHECK("maxpool2_bf16_bwd");
+  return 0;
+}

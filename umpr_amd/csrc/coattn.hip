@@ -130,6 +130,115 @@ __global__ __launch_bounds__(256) void coattn_scores_kernel(ScoreParams p) {
   }
 }
 
+// The same tile loop with the score contraction on v_mfma_f32_32x32x16_bf16 (BASELINE.json configs[4]: "MFMA bf16 ...
+// attention"): T and G_u rows are rounded to bf16 when they are staged, products accumulate in fp32, tanh / max /
+// argmax stay fp32.  LDS rows of 128 bf16 are padded to 136 (272 B = 17 slots of 16 B): conflict-free ds_read_b128.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void coattn_scores_bf16_kernel(ScoreParams p) {
+  constexpr int LDB = 136;
+  __shared__ __attribute__((aligned(16))) __bf16 Ts[64 * LDB];
+  __shared__ __attribute__((aligned(16))) __bf16 Us[64 * LDB];
+  __shared__ float xv[2][64]; __shared__ int xi[2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wu = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int SL = p.SL;
+  const int j0 = blk * 64;
+  const float* Tb = p.T + (long)b * SL * D;
+  const float* Ub = p.Gu + (long)b * SL * D;
+  auto stage = [&](const float* src, int row0, __bf16* dst) {
+    for (int e = tid; e < 64 * (D / 4); e += 256) {
+      const int j = e / (D / 4), c4 = (e % (D / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + j < SL) v = *reinterpret_cast<const float4*>(src + (long)(row0 + j) * D + c4);
+      bf16x4_t o;
+      o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4_t*>(dst + j * LDB + c4) = o;
+    }
+  };
+  stage(Tb, j0, Ts);
+  float rbest[16]; int ridx[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { rbest[r] = -INFINITY; ridx[r] = 0x7fffffff; }
+  const int ntile = (SL + 63) / 64;
+  for (int ut = 0; ut < ntile; ++ut) {
+    const int k0 = ut * 64;
+    __syncthreads();
+    stage(Ub, k0, Us);
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ts + (wi * 32 + l31) * LDB + ks * 16 + 8 * kh);
+      const bf16x8_t u = *reinterpret_cast<const bf16x8_t*>(Us + (wu * 32 + l31) * LDB + ks * 16 + 8 * kh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, u, acc, 0, 0, 0);
+    }
+    const int kcol = k0 + wu * 32 + l31;
+    const bool kvalid = kcol < SL;
+    float cbest = -INFINITY; int cidx = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + wi * 32 + mfma_row(r, lane);
+      const float a = tanhf(acc[r]);
+      if (kvalid && j < SL) {
+        better_first(rbest[r], ridx[r], a, kcol);
+        better_first(cbest, cidx, a, j);
+      }
+    }
+    {
+      const float ov = __shfl_xor(cbest, 32, 64);
+      const int oi = __shfl_xor(cidx, 32, 64);
+      better_first(cbest, cidx, ov, oi);
+    }
+    if (wi == 1 && kh == 0) { xv[wu][l31] = cbest; xi[wu][l31] = cidx; }
+    __syncthreads();
+    if (wi == 0 && kh == 0) {
+      better_first(cbest, cidx, xv[wu][l31], xi[wu][l31]);
+      if (kvalid) {
+        const long o = ((long)b * p.nblk + blk) * SL + kcol;
+        p.colmax_part[o] = cbest;
+        p.argcol_part[o] = cidx;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = rbest[r]; int i = ridx[r];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(i, o, 64);
+      better_first(v, i, ov, oi);
+    }
+    rbest[r] = v; ridx[r] = i;
+  }
+  if (wu == 1 && l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jr = wi * 32 + mfma_row(r, lane);
+      xv[0][jr] = rbest[r]; xi[0][jr] = ridx[r];
+    }
+  }
+  __syncthreads();
+  if (wu == 0 && l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jr = wi * 32 + mfma_row(r, lane);
+      float v = rbest[r]; int i = ridx[r];
+      better_first(v, i, xv[0][jr], xi[0][jr]);
+      if (j0 + jr < SL) {
+        p.rowmax[(long)b * SL + j0 + jr] = v;
+        p.argrow[(long)b * SL + j0 + jr] = i;
+      }
+    }
+  }
+}
+
 __device__ float block_sum(float v, float* red) {
   v = wave_sum(v);
   __syncthreads();
@@ -341,7 +450,7 @@ size_t umpr_coattn_fwd_ws_bytes(int B, int SL) {
 
 int umpr_coattn_fwd_impl(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
                          float* soft_i, float* atte_u, long ld_u, float* atte_i, long ld_i, float* colmax, int* argcol,
-                         float* rowmax, int* argrow, float* ws, size_t ws_bytes, hipStream_t s) {
+                         float* rowmax, int* argrow, float* ws, size_t ws_bytes, hipStream_t s, int bf16_scores) {
   UMPR_REQUIRE(B > 0 && SL > 0, "coattn: bad shape");
   UMPR_REQUIRE(ws_bytes >= umpr_coattn_fwd_ws_bytes(B, SL), "coattn: workspace too small");
   const int nblk = cdiv(SL, 64);
@@ -351,7 +460,8 @@ int umpr_coattn_fwd_impl(const float* Gu, const float* Gi, const float* M, int B
   float* cpart = ws;
   int* apart = reinterpret_cast<int*>(ws + (size_t)B * nblk * SL);
   ScoreParams sp{T, Gu, rowmax, argrow, cpart, apart, SL, nblk};
-  coattn_scores_kernel<<<dim3(nblk, B), 256, 0, s>>>(sp);
+  if (bf16_scores) coattn_scores_bf16_kernel<<<dim3(nblk, B), 256, 0, s>>>(sp);
+  else coattn_scores_kernel<<<dim3(nblk, B), 256, 0, s>>>(sp);
   UMPR_LAUNCH_CHECK("coattn_scores");
   FinishParams fp{Gu, Gi, cpart, apart, nblk, rowmax, colmax, argcol, soft_u, soft_i, atte_u, ld_u, atte_i, ld_i, SL};
   coattn_finish_kernel<<<B, 256, 2 * SL * sizeof(float), s>>>(fp);

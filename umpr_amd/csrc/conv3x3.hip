@@ -1227,6 +1227,17 @@ int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, in
   return 0;
 }
 
+// dW[co][ci][t] (+)= sum over splits of slab[split][t][co][ci]; db likewise from bslab (may be null)
+int umpr_wgrad_reduce(const float* slab, const float* bslab, int splits, int Cout, int Cin, float* dw, float* db,
+                      int accumulate, hipStream_t s) {
+  const long total = (long)9 * Cout * Cin + ((db && bslab) ? Cout : 0);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  wgrad_reduce_kernel<<<blocks, 256, 0, s>>>(slab, (db && bslab) ? bslab : nullptr, splits, Cout, Cin, dw, db, accumulate);
+  UMPR_LAUNCH_CHECK("wgrad_reduce");
+  return 0;
+}
+
 int umpr_maxpool2_fwd_impl(const float* x, float* y, long planes, int H, int W, hipStream_t s) {
   UMPR_REQUIRE((H % 2) == 0 && (W % 2) == 0, "maxpool2: odd extent %dx%d", H, W);
   const long total = planes * (H / 2) * (W / 2);

@@ -63,6 +63,31 @@ int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, in
 int umpr_maxpool2_fwd_impl(const float* x, float* y, long planes, int H, int W, hipStream_t s);
 int umpr_maxpool2_bwd_relu_impl(const float* x, const float* gy, float* gx, long planes, int H, int W, hipStream_t s);
 
+int umpr_wgrad_reduce(const float* slab, const float* bslab, int splits, int Cout, int Cin, float* dw, float* db,
+                      int accumulate, hipStream_t s);
+
+// bf16_conv.hip - bf16 mixed-precision conv stack on CB8-PF tensors (see the file header for the layout)
+struct UmprPF {      // padded-flat geometry of N images of H x W
+  int N, H, W, RW;   // RW = W + 1: row pitch in pixels (column 0 is the zero pad)
+  long rows;         // N * (H + 1) + 1 map rows incl. the zero rows before / between / after the images
+  long ptot;         // rows * RW: pixels [0, ptot) are produced by the kernels
+  long lead, tail;   // zeroed guard pixels in front of pixel 0 and behind ptot
+  long ps;           // plane stride in pixels = lead + ptot + tail (multiple of 64)
+};
+UmprPF umpr_pf(int N, int H, int W);
+size_t umpr_pf_bytes(const UmprPF& g, int C);
+size_t umpr_conv_bf16_pack_bytes(int Cin, int Cout);
+int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const float* bias, const void* mask, void* y,
+                       const UmprPF& g, int Cin, int Cout, int relu, void* wpack, size_t wpack_bytes, hipStream_t s);
+size_t umpr_wgrad_bf16_ws_bytes(const UmprPF& g, int Cin, int Cout);
+int umpr_wgrad_bf16_run(const void* dy, const void* x, float* dw, float* db, const UmprPF& g, int Cin, int Cout,
+                        int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
+int umpr_nchw_to_cb8(const float* x, void* y, const UmprPF& g, int C, hipStream_t s);
+int umpr_cb8_to_nchw(const void* x, float* y, const UmprPF& g, int C, hipStream_t s);
+int umpr_maxpool2_bf16_fwd_run(const void* x, void* y, const UmprPF& gi, const UmprPF& go, int C, hipStream_t s);
+int umpr_maxpool2_bf16_bwd_run(const void* x, const void* gy, void* gx, const UmprPF& gi, const UmprPF& go, int C,
+                               hipStream_t s);
+
 // gru.hip
 int umpr_colsum_rows(const float* src, int rows, long cols, long row_stride, float* dst, int accumulate, hipStream_t s);
 int umpr_gru_recurrent_fwd(const float* gx, const float* whh_f, const float* bhh_f, const float* whh_r,
@@ -77,7 +102,7 @@ int umpr_gru_bptt(const float* dout, const float* out, const float* saved, const
 size_t umpr_coattn_fwd_ws_bytes(int B, int SL);
 int umpr_coattn_fwd_impl(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
                          float* soft_i, float* atte_u, long ld_u, float* atte_i, long ld_i, float* colmax, int* argcol,
-                         float* rowmax, int* argrow, float* ws, size_t ws_bytes, hipStream_t s);
+                         float* rowmax, int* argrow, float* ws, size_t ws_bytes, hipStream_t s, int bf16_scores = 0);
 size_t umpr_coattn_bwd_ws_bytes(int B, int SL);
 int umpr_coattn_bwd_impl(const float* Gu, const float* Gi, const float* M, const float* T, const float* soft_u,
                          const float* soft_i, const float* colmax, const int* argcol, const float* rowmax,
@@ -130,7 +155,8 @@ enum UmprKernelFamily { UMPR_K_CONV_IGEMM = 0, UMPR_K_CONV_WGRAD = 1, UMPR_K_GEM
                         UMPR_K_WINO_GEMM = 4 /* nested inside CONV_IGEMM: executed MFMA FLOPs of the Winograd GEMM */,
                         UMPR_K_CONV_DGRAD = 5 /* the conv kernels of family 0 run as data gradient */,
                         UMPR_K_WINO_WGRAD_GEMM = 6 /* nested inside CONV_WGRAD: executed FLOPs of the Winograd wgrad GEMM */,
-                        UMPR_K_COUNT = 7 };
+                        UMPR_K_B16_FWD = 7, UMPR_K_B16_DGRAD = 8, UMPR_K_B16_WGRAD = 9 /* bf16 conv kernels (bf16_conv.hip) */,
+                        UMPR_K_COUNT = 10 };
 struct UmprProfScope {
   UmprProfScope(int family, double work, hipStream_t s);
   ~UmprProfScope();

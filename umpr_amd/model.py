@@ -73,7 +73,7 @@ class _ReviewHead(torch.autograd.Function):
     """R-Net co-attention + S-Net(u) + S-Net(i) + textual matching (src/model.py:50-55, 71-81, 162-168)."""
 
     @staticmethod
-    def forward(ctx, gru_u, gru_i, S, L, M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i):
+    def forward(ctx, gru_u, gru_i, S, L, M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i, bf16=False):
         B, SL, _ = gru_u.shape
         dev = gru_u.device
         f = dict(device=dev, dtype=torch.float32)
@@ -86,8 +86,8 @@ class _ReviewHead(torch.autograd.Function):
         repr_u, repr_i = torch.empty(B, 2 * D, **f), torch.empty(B, 2 * D, **f)
         ws, wsb = _ws(lib().size("umpr_coattention_fwd_ws_bytes", B, SL), dev)
         st = stream_ptr()
-        lib().call("umpr_coattention_fwd", gru_u, gru_i, M, B, SL, T, soft_u, soft_i, repr_u, 2 * D, repr_i, 2 * D,
-                   colmax, argcol, rowmax, argrow, ws, wsb, st)
+        lib().call("umpr_coattention_fwd_bf16" if bf16 else "umpr_coattention_fwd", gru_u, gru_i, M, B, SL, T, soft_u,
+                   soft_i, repr_u, 2 * D, repr_i, 2 * D, colmax, argcol, rowmax, argrow, ws, wsb, st)
         sn = []
         for X, Ms, Ws, soft, rep in ((gru_u, Ms_u, Ws_u, soft_u, repr_u), (gru_i, Ms_i, Ws_i, soft_i, repr_i)):
             U = torch.empty(B, S, L, AT, **f)
@@ -131,7 +131,7 @@ class _ReviewHead(torch.autograd.Function):
         ws, wsb = _ws(lib().size("umpr_coattention_bwd_ws_bytes", B, SL), dev)
         lib().call("umpr_coattention_bwd", gru_u, gru_i, M, T, soft_u, soft_i, colmax, argcol, rowmax, argrow,
                    d_repr_u, 2 * D, d_repr_i, 2 * D, dsoft[0], dsoft[1], B, SL, dG[0], dG[1], dM, 1, ws, wsb, st)
-        return dG[0], dG[1], None, None, dM, dMs[0], dWs[0], dMs[1], dWs[1], dW_u, dW_i
+        return dG[0], dG[1], None, None, dM, dMs[0], dWs[0], dMs[1], dWs[1], dW_u, dW_i, None
 
 
 # --------------------------------------------------------------------------------------------- K8-K9
@@ -278,23 +278,62 @@ class _VGGFeatures(torch.autograd.Function):
         return (None, *_grad_returns(ctx.param_objs, grads, direct))
 
 
+class _VGGFeaturesBF16(torch.autograd.Function):
+    """The same convolutional stage in bf16 mixed precision (BASELINE.json configs[4]): bf16 activations / gradients in
+    the library's CB8-PF layout, fp32 accumulation, fp32 master weights and weight gradients.  Returns (pool5 [n,25088]
+    fp32 - a view into the compact classifier arena -, that arena)."""
+
+    @staticmethod
+    def forward(ctx, images, *params):
+        n = images.shape[0]
+        assert tuple(images.shape[1:]) == (3, 224, 224), "VGG16 kernels take 3x224x224 images (src/dataset.py:146)"
+        dev = images.device
+        images = _c(images)
+        params_in = params
+        params = [_c(p) for p in params]
+        acts = torch.empty(lib().size("umpr_vgg16_bf16_act_bytes", n), device=dev, dtype=torch.uint8)
+        cls = torch.empty(lib().size("umpr_vgg16_cls_arena_bytes", n) // 4, device=dev, dtype=torch.float32)
+        ws, wsb = _ws(lib().size("umpr_vgg16_bf16_fwd_ws_bytes", n), dev)
+        keep, parr = _ptr_array(params + params[:6])
+        lib().call("umpr_vgg16_bf16_features_fwd", images, parr, n, acts, cls, ws, wsb, stream_ptr())
+        pool5 = cls[:n * 25088].view(n, 25088)
+        ctx.save_for_backward(images, acts, *params)
+        ctx.param_objs = params_in
+        ctx.mark_non_differentiable(cls)
+        return pool5, cls
+
+    @staticmethod
+    def backward(ctx, d_pool5, _):
+        images, acts, *params = ctx.saved_tensors
+        n = images.shape[0]
+        dev = images.device
+        grads, direct = _grad_targets(ctx.param_objs)
+        ws, wsb = _ws(lib().size("umpr_vgg16_bf16_bwd_ws_bytes", n), dev)
+        keep_p, parr = _ptr_array(params + params[:6])
+        keep_g, garr = _ptr_array(grads + grads[:6])
+        lib().call("umpr_vgg16_bf16_features_bwd", images, parr, n, acts, _c(d_pool5), garr, ws, wsb, stream_ptr())
+        return (None, *_grad_returns(ctx.param_objs, grads, direct))
+
+
 class _VGGClassifier(torch.autograd.Function):
     """Linear(25088,4096)-ReLU-Dropout-Linear(4096,4096)-ReLU-Dropout-Linear(4096,1000) on the pooled features."""
 
     @staticmethod
-    def forward(ctx, pool5, acts, train, masks_in, seed, owner, *params):
+    def forward(ctx, pool5, acts, train, masks_in, seed, owner, compact, *params):
+        """`acts`: the fp32 activation arena of _VGGFeatures, or (compact) the classifier arena of _VGGFeaturesBF16."""
         n = pool5.shape[0]
         dev = pool5.device
         ctx.param_objs = params
         ctx.owner = owner
+        ctx.suffix = "_compact" if compact else ""
         params = [_c(p) for p in params]
         use_masks = masks_in is not None
         masks = _c(masks_in) if use_masks else torch.empty(2, n, 4096, device=dev, dtype=torch.uint8)
         out = torch.empty(n, 1000, device=dev, dtype=torch.float32)
         ws, wsb = _ws(lib().size("umpr_vgg16_fwd_ws_bytes", n), dev)
         keep, parr = _ptr_array([params[0]] * 26 + params)   # slots 26..31 = classifier
-        lib().call("umpr_vgg16_classifier_fwd", parr, n, int(train), int(use_masks), int(seed), acts, masks, out, ws,
-                   wsb, stream_ptr())
+        lib().call("umpr_vgg16_classifier_fwd" + ctx.suffix, parr, n, int(train), int(use_masks), int(seed), acts, masks,
+                   out, ws, wsb, stream_ptr())
         ctx.dropout = bool(train) or use_masks
         ctx.save_for_backward(acts, masks, *params)
         return out
@@ -309,13 +348,13 @@ class _VGGClassifier(torch.autograd.Function):
         ws, wsb = _ws(lib().size("umpr_vgg16_classifier_bwd_ws_bytes", n), dev)
         keep_p, parr = _ptr_array([params[0]] * 26 + params)
         keep_g, garr = _ptr_array([grads[0]] * 26 + grads)
-        lib().call("umpr_vgg16_classifier_bwd", parr, n, int(ctx.dropout), acts, masks, _c(d_out), garr, d_pool5, ws,
-                   wsb, stream_ptr())
+        lib().call("umpr_vgg16_classifier_bwd" + ctx.suffix, parr, n, int(ctx.dropout), acts, masks, _c(d_out), garr,
+                   d_pool5, ws, wsb, stream_ptr())
         out = _grad_returns(ctx.param_objs, grads, direct)
         if all(direct) and ctx.owner is not None:   # written in place: no AccumulateGrad hook will announce them
             for cb in ctx.owner.grad_callbacks:
                 cb()
-        return (d_pool5, None, None, None, None, None, *out)
+        return (d_pool5, None, None, None, None, None, None, *out)
 
 
 # --------------------------------------------------------------------------------------------- K11-K12
@@ -448,8 +487,10 @@ _VGG_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 
 class VGG16(nn.Module):
     """Layer list of torchvision's vgg16 (cfg "D") so that state_dict keys match ``features.N`` / ``classifier.N``."""
 
-    def __init__(self, num_classes=1000):
+    def __init__(self, num_classes=1000, dtype="fp32"):
         super().__init__()
+        assert dtype in ("fp32", "bf16"), dtype
+        self.compute_dtype = dtype   # "bf16": conv stack on bf16 MFMA with fp32 accumulation (classifier stays fp32)
         layers, cin = [], 3
         for v in _VGG_CFG:
             if v == "M":
@@ -488,16 +529,17 @@ class VGG16(nn.Module):
         self._calls += 1
         seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
         ps = self.param_list()
-        pool5, acts = _VGGFeatures.apply(images, *ps[:26])
-        return _VGGClassifier.apply(pool5, acts, self.training, self.dropout_masks, seed, self, *ps[26:])
+        bf16 = self.compute_dtype == "bf16"
+        pool5, acts = (_VGGFeaturesBF16 if bf16 else _VGGFeatures).apply(images, *ps[:26])
+        return _VGGClassifier.apply(pool5, acts, self.training, self.dropout_masks, seed, self, bf16, *ps[26:])
 
 
 class VisualNet(nn.Module):
-    def __init__(self, view_size, vgg_out=1000, vgg_weights=None):
+    def __init__(self, view_size, vgg_out=1000, vgg_weights=None, dtype="fp32"):
         super().__init__()
         # The reference asks torchvision for ImageNet weights (pretrained=True, src/model.py:205): a network fetch.
         # Offline the stack is randomly initialised; pass vgg_weights=<local vgg16 state_dict .pth> to load a file.
-        self.vgg16 = nn.Sequential(VGG16(vgg_out))
+        self.vgg16 = nn.Sequential(VGG16(vgg_out, dtype=dtype))
         if vgg_weights:
             self.vgg16[0].load_state_dict(torch.load(vgg_weights, map_location="cpu", weights_only=True))
         self.pos_v_emb = nn.Parameter(torch.randn(view_size, vgg_out))
@@ -510,6 +552,10 @@ class UMPR(nn.Module):
         super().__init__()
         self.review_net_only = config.review_net_only
         self.loss_v_rate = config.loss_v_rate
+        # not in the reference: `--dtype bf16` = mixed precision (BASELINE.json configs[4]) - bf16 MFMA for the VGG conv
+        # stack and the co-attention scores, fp32 accumulation, fp32 master weights / GRU gates / softmax / Adam
+        self.compute_dtype = str(getattr(config, "dtype", "fp32"))
+        assert self.compute_dtype in ("fp32", "bf16"), f"dtype must be fp32 or bf16, got {self.compute_dtype}"
         # one wave handles one sentence in the S-Net / C-Net kernels: at most 64 tokens per sentence (config.py:29 uses 20;
         # review_level='review' with a longer max_sent_length would exceed it)
         assert int(getattr(config, "max_sent_length", 20)) <= 64, "max_sent_length > 64 is not supported by the S-Net kernels"
@@ -522,7 +568,8 @@ class UMPR(nn.Module):
             view_size = len(config.views)
             self.control_net = ControlNet(E, config.gru_size, config.kernel_count, config.kernel_size, view_size,
                                           config.threshold, config.self_atte_size)
-            self.visual_net = VisualNet(view_size, vgg_weights=getattr(config, "vgg_weights", None))
+            self.visual_net = VisualNet(view_size, vgg_weights=getattr(config, "vgg_weights", None),
+                                        dtype=self.compute_dtype)
             self.linear_fusion = nn.Sequential(nn.Linear(config.gru_size * 2 + view_size + view_size, 1), nn.ReLU())
         self.last_loss_terms = None
 
@@ -549,7 +596,7 @@ class UMPR(nn.Module):
         gru_u = rn.r_net.gru(user_reviews.view(B * S, L), lu, ou, emb).view(B, S * L, D)
         gru_i = rn.r_net.gru(item_reviews.view(B * S, L), li, oi, emb).view(B, S * L, D)
         return _ReviewHead.apply(gru_u, gru_i, S, L, rn.r_net.M, rn.s_net_u.Ms, rn.s_net_u.Ws, rn.s_net_i.Ms,
-                                 rn.s_net_i.Ws, rn.linear_u.weight, rn.linear_i.weight)
+                                 rn.s_net_i.Ws, rn.linear_u.weight, rn.linear_i.weight, self.compute_dtype == "bf16")
 
     def _control(self, user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui, emb):
         B, S, L = user_reviews.shape
