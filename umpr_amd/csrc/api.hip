@@ -598,10 +598,9 @@ VggB16Layout vgg_b16_layout(int n) {
   return L;
 }
 size_t b16_pack_bytes() { return align_up(umpr_conv_bf16_pack_bytes(512, 512), 1024); }
-size_t b16_first_f32_bytes(int n) { return (size_t)n * 64 * 224 * 224 * sizeof(float); }
 size_t b16_wgrad_ws_bytes(int n) {
   const VggB16Layout L = vgg_b16_layout(n);
-  size_t m = umpr_conv3x3_wgrad_ws_bytes(n, 3, 64, 224, 224);      // first layer: fp32 kernel
+  size_t m = umpr_conv1_bf16_wgrad_ws_bytes();
   for (int i = 1; i < 13; ++i) {
     const size_t b = umpr_wgrad_bf16_ws_bytes(L.geo[L.conv_block[i]], L.conv_cin[i], L.conv_cout[i]);
     if (b > m) m = b;
@@ -647,12 +646,12 @@ int umpr_maxpool2_bf16_bwd_relu(const void* x, const void* dy, void* dx, int N, 
 }
 
 size_t umpr_vgg16_bf16_act_bytes(int n_img) { return vgg_b16_layout(n_img).total; }
-// forward scratch: [packed weights][fp32 output of the first conv]
-size_t umpr_vgg16_bf16_fwd_ws_bytes(int n_img) { return b16_pack_bytes() + b16_first_f32_bytes(n_img); }
-// backward scratch: [3 rotating gradient slots][packed weights][wgrad slabs][fp32 gradient of the first conv's output]
+// forward scratch: [packed weights]
+size_t umpr_vgg16_bf16_fwd_ws_bytes(int n_img) { (void)n_img; return b16_pack_bytes(); }
+// backward scratch: [3 rotating gradient slots][packed weights][wgrad slabs]
 size_t umpr_vgg16_bf16_bwd_ws_bytes(int n_img) {
   const size_t slot = align_up(umpr_pf_bytes(umpr_pf(n_img, 224, 224), 64), 1024);
-  return 3 * slot + b16_pack_bytes() + b16_wgrad_ws_bytes(n_img) + b16_first_f32_bytes(n_img);
+  return 3 * slot + b16_pack_bytes() + b16_wgrad_ws_bytes(n_img);
 }
 
 // Convolutional stage in bf16 (activations kept in `acts` for the backward pass); pool5 [n][25088] fp32 out, in the
@@ -664,10 +663,8 @@ int umpr_vgg16_bf16_features_fwd(const float* images, const float* const* params
   const VggB16Layout L = vgg_b16_layout(n);
   hipStream_t s = S(stream);
   void* wpack = ws;
-  float* f32 = reinterpret_cast<float*>(BP(ws) + b16_pack_bytes());
-  // first layer (3 input channels, K = 27): the fp32 first-layer kernel, then one conversion pass to CB8-PF bf16
-  if (int rc = umpr_conv3x3_run(images, params[0], 0, params[1], nullptr, f32, n, 3, 64, 224, 224, 1, nullptr, 0, s)) return rc;
-  if (int rc = umpr_nchw_to_cb8(f32, BP(acts) + L.conv_off[0], L.geo[0], 64, s)) return rc;
+  // first layer (3 input channels, K = 27 padded to 32): its own kernel, fp32 image in, bf16 CB8-PF out
+  if (int rc = umpr_conv1_bf16_fwd(images, params[0], params[1], BP(acts) + L.conv_off[0], L.geo[0], s)) return rc;
   const void* x = BP(acts) + L.conv_off[0];
   int ci = 1;
   for (int b = 0; b < 5; ++b) {
@@ -694,36 +691,56 @@ int umpr_vgg16_bf16_features_bwd(const float* images, const float* const* params
   void* wpack = BP(ws) + 3 * slot;
   float* slabs = reinterpret_cast<float*>(BP(ws) + 3 * slot + b16_pack_bytes());
   const size_t slab_bytes = b16_wgrad_ws_bytes(n);
-  float* f32 = reinterpret_cast<float*>(BP(ws) + 3 * slot + b16_pack_bytes() + slab_bytes);
+  // weight gradients on the library's side stream, exactly as in the fp32 path (umpr_vgg16_features_bwd): `ready[ci]`
+  // gates the wgrad of layer ci behind its output gradient, `done[ci]` gates the reuse of that gradient's slot
+  const bool side = g_wgrad_side && g_wside.init();
+  hipStream_t sw = side ? g_wside.stream : s;
+  int slot_reader[3] = {-1, -1, -1};
   int nxt = 0;
-  auto claim = [&]() -> char* { char* p = buf[nxt]; nxt = (nxt + 1) % 3; return p; };
+  auto claim = [&]() -> int {
+    const int k = nxt; nxt = (nxt + 1) % 3;
+    if (side && slot_reader[k] >= 0) { (void)hipStreamWaitEvent(s, g_wside.done[slot_reader[k]], 0); slot_reader[k] = -1; }
+    return k;
+  };
   // gradient w.r.t. the pooled 7x7 map arrives in fp32 NCHW order from the classifier
-  char* g = claim();
-  if (int rc = umpr_nchw_to_cb8(d_pool5, g, L.pool_geo[4], 512, s)) return rc;
+  int gs = claim();
+  if (int rc = umpr_nchw_to_cb8(d_pool5, buf[gs], L.pool_geo[4], 512, s)) return rc;
   int ci = 12;
   for (int b = 4; b >= 0; --b) {
     // pool backward + ReLU mask of the conv output that fed the pool -> gradient w.r.t. that conv's pre-activation
-    char* cur = claim();
-    if (int rc = umpr_maxpool2_bf16_bwd_run(CBP(acts) + L.conv_off[ci], g, cur, L.geo[b], L.pool_geo[b], kBlockCh[b], s)) return rc;
-    g = cur;
+    int cs = claim();
+    if (int rc = umpr_maxpool2_bf16_bwd_run(CBP(acts) + L.conv_off[ci], buf[gs], buf[cs], L.geo[b], L.pool_geo[b],
+                                            kBlockCh[b], s)) return rc;
+    gs = cs;
     for (int j = kConvPerBlock[b] - 1; j >= 0; --j, --ci) {
       const int cin = L.conv_cin[ci], cout = L.conv_cout[ci];
-      if (ci == 0) {
-        // first layer: gradient back to fp32 NCHW, fp32 weight-gradient kernel on the fp32 images
-        if (int rc = umpr_cb8_to_nchw(g, f32, L.geo[0], 64, s)) return rc;
-        return umpr_conv3x3_wgrad(f32, images, grads[0], grads[1], n, 3, 64, 224, 224, 0, slabs, slab_bytes, s);
+      if (side) {
+        (void)hipEventRecord(g_wside.ready[ci], s);
+        (void)hipStreamWaitEvent(sw, g_wside.ready[ci], 0);
       }
+      if (ci == 0) {
+        if (int rc = umpr_conv1_bf16_wgrad(buf[gs], images, grads[0], grads[1], L.geo[0], 0, slabs, slab_bytes, sw)) return rc;
+      } else {
+        const void* xin = j == 0 ? CBP(acts) + L.pool_off[b - 1] : CBP(acts) + L.conv_off[ci - 1];
+        if (int rc = umpr_wgrad_bf16_run(buf[gs], xin, grads[2 * ci], grads[2 * ci + 1], L.geo[b], cin, cout, 0, slabs,
+                                         slab_bytes, sw)) return rc;
+      }
+      if (side) {
+        (void)hipEventRecord(g_wside.done[ci], sw);
+        slot_reader[gs] = ci;
+      }
+      if (ci == 0) break;
       const void* xin = j == 0 ? CBP(acts) + L.pool_off[b - 1] : CBP(acts) + L.conv_off[ci - 1];
-      if (int rc = umpr_wgrad_bf16_run(g, xin, grads[2 * ci], grads[2 * ci + 1], L.geo[b], cin, cout, 0, slabs,
-                                       slab_bytes, s)) return rc;
       // the input came straight from a conv+ReLU (j > 0): mask by it; from a pool (j == 0): the pool backward masks
       const void* mask = j > 0 ? xin : nullptr;
-      cur = claim();
-      if (int rc = umpr_conv_bf16_run(g, params[2 * ci], 1, nullptr, mask, cur, L.geo[b], cin, cout, 0, wpack,
+      cs = claim();
+      if (int rc = umpr_conv_bf16_run(buf[gs], params[2 * ci], 1, nullptr, mask, buf[cs], L.geo[b], cin, cout, 0, wpack,
                                       b16_pack_bytes(), s)) return rc;
-      g = cur;
+      gs = cs;
     }
+    if (ci == 0 && b == 0) break;
   }
+  if (side) (void)hipStreamWaitEvent(s, g_wside.done[0], 0);   // every weight gradient is complete behind this wait
   return 0;
 }
 

@@ -83,7 +83,7 @@ struct ConvB16Params {
 // W: map width.  TR > 0: 2-D tile of TR rows x TC real columns; TR == 0: 1-D tile of TC consecutive flat pixels.
 // BN output channels per workgroup; WP x WC waves (pixels x channels).
 template <int W, int TR, int TC, int BN, int WP, int WC>
-__global__ __launch_bounds__(64 * WP * WC) void conv_bf16_kernel(ConvB16Params p) {
+__global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf16_kernel(ConvB16Params p) {
   constexpr int NW = WP * WC, NT = 64 * NW;
   constexpr bool TWO_D = TR > 0;
   constexpr int BM = TWO_D ? TR * TC : TC;
@@ -236,6 +236,19 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_bf16_kernel(ConvB16Params p
     const long P = TWO_D ? Q0 + (long)(k / TC) * RW + (k % TC) : Q0 + k;
     if (P >= p.ptot) continue;
     const bool real = pf_real<RW>(P, p.H);
+    // all mask words of this pixel first (independent loads in flight together), then the stores: loaded one by one
+    // between the stores, each would wait out a full memory round trip (the compiler cannot move a load above a store
+    // that may alias it) - that cost the 64-channel data gradient 250 us
+    bf16x4 mk[TCW][4];
+    if (p.mask) {
+#pragma unroll
+      for (int i = 0; i < TCW; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = ct * BN + wco * (BN / WC) + i * 32 + 8 * g + 4 * h;
+          mk[i][g] = *reinterpret_cast<const bf16x4*>(p.mask + ((long)(co >> 3) * p.mps + P) * 8 + (co & 7));
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TCW; ++i) {
 #pragma unroll
@@ -250,9 +263,8 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_bf16_kernel(ConvB16Params p
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.mask) {
-          const bf16x4 m = *reinterpret_cast<const bf16x4*>(p.mask + ((long)(co >> 3) * p.mps + P) * 8 + (co & 7));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (float)m[e] > 0.f ? v[e] : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = (float)mk[i][g][e] > 0.f ? v[e] : 0.f;
         }
         bf16x4 out;
 #pragma unroll
@@ -626,6 +638,163 @@ __global__ void maxpool2_bf16_bwd_relu_kernel(const bf16_t* __restrict__ x, long
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// first VGG layer (3 input channels, K = 27 padded to 32): fp32 NCHW image in, bf16 CB8-PF out.  No LDS, no barriers:
+// every wave keeps the 64 x 32 weight fragments in registers and walks over 32-pixel row segments; the im2col fragment
+// (16 values per lane) is gathered straight from the image (38 MB at batch 64: L2 / Infinity-Cache resident).
+struct Conv1B16Params { const float* x; const float* w; const float* bias; bf16_t* y; long yps; int N, H, W; };
+
+__global__ __launch_bounds__(256) void conv1_bf16_fwd_kernel(Conv1B16Params p) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  const int H = p.H, W = p.W, RW = W + 1;
+  const long HW = (long)H * W;
+  bf16x8 wa[2][2];
+  int doff[16], ddy[16], ddx[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int k = 16 * (q >> 3) + 8 * h + (q & 7);           // k = c * 9 + tap; k >= 27: zero weight, any valid address
+    const int kk = k < 27 ? k : 0;
+    const int c = kk / 9, tap = kk - c * 9;
+    ddy[q] = tap / 3 - 1; ddx[q] = tap % 3 - 1;
+    doff[q] = c * (int)HW + ddy[q] * W + ddx[q];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wa[i][q >> 3][q & 7] = (bf16_t)(k < 27 ? p.w[(i * 32 + r) * 27 + k] : 0.f);
+  }
+  f32x16 b0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) b0[i][x] = p.bias ? p.bias[i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h] : 0.f;
+  const int xt_n = W / 32;
+  const long ntiles = (long)p.N * H * xt_n;
+  for (long t = wave; t < ntiles; t += nwaves) {
+    const int xt = (int)(t % xt_n);
+    const long ny = t / xt_n;
+    const int y = (int)(ny % H);
+    const long n = ny / H;
+    const int x = xt * 32 + r;
+    const float* px = p.x + n * 3 * HW + (long)y * W + x;
+    const bool interior = y > 0 && y < H - 1 && xt > 0 && xt < xt_n - 1;      // wave-uniform
+    bf16x8 bf[2];
+    if (interior) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) bf[q >> 3][q & 7] = (bf16_t)px[doff[q]];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int yy = y + ddy[q], xx = x + ddx[q];
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float v = px[ok ? doff[q] : 0];
+        bf[q >> 3][q & 7] = (bf16_t)(ok ? v : 0.f);
+      }
+    }
+    const long P = (n * (H + 1) + y + 1) * RW + x + 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x16 acc = b0[i];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][0], bf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][1], bf[1], acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = i * 32 + 8 * g + 4 * h;
+        bf16x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = (bf16_t)fmaxf(acc[4 * g + e], 0.f);
+        *reinterpret_cast<bf16x4*>(p.y + ((long)(co >> 3) * p.yps + P) * 8 + (co & 7)) = out;
+      }
+    }
+  }
+}
+
+// zero pads of a CB8-PF tensor whose real pixels are written by a kernel that skips the pads: column 0 of every row and
+// the zero rows before / between / after the images
+__global__ void pf_zero_pads_kernel(bf16_t* __restrict__ y, long yps, int H, int W, long rows) {
+  const int RW = W + 1, cb = blockIdx.y;
+  uint4 z = make_uint4(0, 0, 0, 0);
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    bf16_t* base = y + ((long)cb * yps + row * RW) * 8;
+    if (row % (H + 1) == 0) {
+      for (int c = threadIdx.x; c < RW; c += blockDim.x) *reinterpret_cast<uint4*>(base + (long)c * 8) = z;
+    } else if (threadIdx.x == 0) {
+      *reinterpret_cast<uint4*>(base) = z;
+    }
+  }
+}
+
+// first layer's weight gradient: dW[co][c*9+tap] = sum_P dY[P][co] * x[P + off(tap)][c] with dY in bf16 CB8-PF and the
+// fp32 image.  M = 64 output channels (two accumulator tiles), N = 27 (one tile of 32 columns), K = pixels in steps of
+// 16 along a row.  Both fragments are gathered straight from memory (each dY element exactly once in the whole launch, the
+// image from L2): no LDS in the loop; the waves of a workgroup are summed through LDS at the end, workgroups write
+// split-K slabs [split][9][64][3] for the shared reduce kernel.
+struct Wgrad1B16Params { const bf16_t* dy; long dps; const float* x; float* slab; int N, H, W; };
+
+__global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(Wgrad1B16Params p) {
+  __shared__ float red[3][2][16][64];
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  const long wave = (long)blockIdx.x * 4 + wv, nwaves = (long)gridDim.x * 4;
+  const int H = p.H, W = p.W, RW = W + 1;
+  const long HW = (long)H * W;
+  const int col = r < 27 ? r : 0;
+  const int c = col / 9, tap = col - c * 9, dy_ = tap / 3 - 1, dx_ = tap % 3 - 1;
+  const bool colok = r < 27;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[i][x] = 0.f;
+  const int ks_n = W / 16;
+  const long nsteps = (long)p.N * H * ks_n;
+  for (long t = wave; t < nsteps; t += nwaves) {
+    const int kx = (int)(t % ks_n);
+    const long ny = t / ks_n;
+    const int y = (int)(ny % H);
+    const long n = ny / H;
+    const int x0 = kx * 16 + 8 * h;                              // this lane half's 8 pixels x0 .. x0+7 of row y
+    const long P = (n * (H + 1) + y + 1) * RW + x0 + 1;
+    // A[row = co][k = pixel]: 8 consecutive pixels of channel co = i*32 + r: 2-byte gathers at a 16-B stride
+    bf16x8 a[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int co = i * 32 + r;
+      const bf16_t* g = p.dy + ((long)(co >> 3) * p.dps + P) * 8 + (co & 7);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[i][j] = g[j * 8];
+    }
+    // B[k = pixel][col = (c, tap)]: the image at (y + dy, x0 + j + dx), zero outside
+    bf16x8 b;
+    const int yy = y + dy_;
+    const bool rowok = colok && yy >= 0 && yy < H;
+    const float* px = p.x + (n * 3 + c) * HW + (long)(rowok ? yy : 0) * W;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int xx = x0 + j + dx_;
+      const bool ok = rowok && xx >= 0 && xx < W;
+      const float v = px[ok ? xx : 0];
+      b[j] = (bf16_t)(ok ? v : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i], 0, 0, 0);
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) red[wv - 1][i][x][lane] = acc[i][x];
+  }
+  __syncthreads();
+  if (wv == 0 && colok) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const float v = acc[i][x] + ((red[0][i][x][lane] + red[1][i][x][lane]) + red[2][i][x][lane]);
+        const int co = i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+        p.slab[(((long)blockIdx.x * 9 + tap) * 64 + co) * 3 + c] = v;
+      }
+  }
+}
+
 inline int grid_for(long n, int cap) {
   long b = (n + 255) / 256;
   if (b > cap) b = cap;
@@ -644,22 +813,25 @@ void launch_conv(ConvB16Params p, hipStream_t s) {
   conv_bf16_kernel<W, TR, TC, BN, WP, WC><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
 }
 
-// tile choice per map width and output-channel count (all 8 waves):
-//   M % 256 == 0 : 256 pixels x 256 channels, waves 2 x 4 (each 128 px x 64 ch)
-//   M % 128 == 0 : 256 x 128, waves 4 x 2 (64 x 64)
-//   else (64)    : 512 x 64, waves 8 x 1 (64 x 64)
-template <int W, int TR256, int TC256, int TR512, int TC512>
+// tile choice per map width and output-channel count:
+//   M % 256 == 0 : 256 pixels x 256 channels, 8 waves 2 x 4 (each 128 px x 64 ch), one workgroup per CU
+//   M % 128 == 0 : 256 x 128, 8 waves 4 x 2 (64 x 64)
+//   else (64)    : 256 x 64, 4 waves 4 x 1 (64 x 64), 66 KB of LDS: two workgroups per CU, so one's prologue / epilogue
+//                  (K is only 576 deep there) hides behind the other's main loop
+//   14 x 14 maps : 57 pixel tiles only - 128-channel tiles (4 x 57 = 228 workgroups) fill the 256 CUs, 256-channel
+//                  tiles (114) would leave half of them idle
+template <int W, int TR, int TC>
 int dispatch_conv_w(const ConvB16Params& p, hipStream_t s) {
-  if (p.M % 256 == 0) launch_conv<W, TR256, TC256, 256, 2, 4>(p, s);
-  else if (p.M % 128 == 0) launch_conv<W, TR256, TC256, 128, 4, 2>(p, s);
-  else if (p.M % 64 == 0) launch_conv<W, TR512, TC512, 64, 8, 1>(p, s);
+  if (p.M % 256 == 0 && W != 14) launch_conv<W, TR, TC, 256, 2, 4>(p, s);
+  else if (p.M % 128 == 0) launch_conv<W, TR, TC, 128, 4, 2>(p, s);
+  else if (p.M % 64 == 0) launch_conv<W, TR, TC, 64, 4, 1>(p, s);
   else return -1;
   return 0;
 }
 
-int conv_bn_for(int M) { return M % 256 == 0 ? 256 : (M % 128 == 0 ? 128 : 64); }
+int conv_bn_for(int M, int W) { return (M % 256 == 0 && W != 14) ? 256 : (M % 128 == 0 ? 128 : 64); }
 
-constexpr int kWgradB16Wgs = 512;   // workgroups per launch the split-K factor aims at (2 rounds of 256 CUs)
+constexpr int kWgradB16Wgs = 256;   // workgroups per launch the split-K factor aims at: one per CU (LDS admits one)
 
 // segment / tile / split-K plan of a weight-gradient launch (shared by the workspace query and the launch)
 struct WgradPlan { bool big; long nseg; int ntiles, ncit, splits, segs_per_split; };
@@ -702,7 +874,7 @@ int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const floa
   UMPR_REQUIRE(g.H == g.W && (g.W == 224 || g.W == 112 || g.W == 56 || g.W == 28 || g.W == 14),
                "conv_bf16: map %dx%d is not a VGG16 map size", g.H, g.W);
   UMPR_REQUIRE(wpack_bytes >= umpr_conv_bf16_pack_bytes(Cin, Cout), "conv_bf16: weight scratch too small");
-  const int BN = conv_bn_for(M);
+  const int BN = conv_bn_for(M, g.W);
   bf16_t* wp = static_cast<bf16_t*>(wpack);
   pack_weights_bf16_kernel<<<grid_for((long)M * C * 9, 2048), 256, 0, s>>>(w, wp, M, C, Cin, BN, transposed);
   UMPR_LAUNCH_CHECK("pack_weights_bf16");
@@ -718,11 +890,11 @@ int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const floa
   UmprProfScope prof(transposed ? UMPR_K_B16_DGRAD : UMPR_K_B16_FWD, 2.0 * (double)g.ptot * M * C * 9, s);
   int rc;
   switch (g.W) {
-    case 224: rc = dispatch_conv_w<224, 8, 32, 16, 32>(p, s); break;
-    case 112: rc = dispatch_conv_w<112, 16, 16, 32, 16>(p, s); break;
-    case 56: rc = dispatch_conv_w<56, 0, 256, 0, 512>(p, s); break;
-    case 28: rc = dispatch_conv_w<28, 0, 256, 0, 512>(p, s); break;
-    default: rc = dispatch_conv_w<14, 0, 256, 0, 512>(p, s); break;
+    case 224: rc = dispatch_conv_w<224, 8, 32>(p, s); break;
+    case 112: rc = dispatch_conv_w<112, 16, 16>(p, s); break;
+    case 56: rc = dispatch_conv_w<56, 0, 256>(p, s); break;
+    case 28: rc = dispatch_conv_w<28, 0, 256>(p, s); break;
+    default: rc = dispatch_conv_w<14, 0, 256>(p, s); break;
   }
   UMPR_REQUIRE(rc == 0, "conv_bf16: unsupported channel count %d", M);
   UMPR_LAUNCH_CHECK("conv_bf16");
@@ -812,4 +984,40 @@ int umpr_maxpool2_bf16_bwd_run(const void* x, const void* gy, void* gx, const Um
       g0 + gi.lead * 8, gi.ps, gi.H, gi.W, gi.ptot);
   UMPR_LAUNCH_CHECK("maxpool2_bf16_bwd");
   return 0;
+}
+
+// first VGG layer in the bf16 path: fp32 images [N][3][H][W] -> bf16 CB8-PF [64 channels], ReLU fused
+int umpr_conv1_bf16_fwd(const float* x, const float* w, const float* bias, void* y, const UmprPF& g, hipStream_t s) {
+  UMPR_REQUIRE(g.W % 32 == 0, "conv1_bf16: width %d is not a multiple of 32", g.W);
+  bf16_t* y0 = static_cast<bf16_t*>(y);
+  zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), 8), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);
+  pf_zero_pads_kernel<<<dim3((unsigned)(g.rows < 4096 ? g.rows : 4096), 8), 64, 0, s>>>(y0 + g.lead * 8, g.ps, g.H, g.W, g.rows);
+  Conv1B16Params p{x, w, bias, y0 + g.lead * 8, g.ps, g.N, g.H, g.W};
+  UmprProfScope prof(UMPR_K_B16_FWD, 2.0 * (double)g.N * g.H * g.W * 64 * 27, s);
+  conv1_bf16_fwd_kernel<<<2048, 256, 0, s>>>(p);
+  UMPR_LAUNCH_CHECK("conv1_bf16_fwd");
+  return 0;
+}
+
+constexpr int kWgrad1Splits = 512;
+size_t umpr_conv1_bf16_wgrad_ws_bytes() { return (size_t)kWgrad1Splits * (9 * 64 * 3 + 64) * sizeof(float) + 1024; }
+
+// dw [64][3][3][3], db [64] from dY (bf16 CB8-PF, 64 channels) and the fp32 images
+int umpr_conv1_bf16_wgrad(const void* dy, const float* x, float* dw, float* db, const UmprPF& g, int accumulate,
+                          float* ws, size_t ws_bytes, hipStream_t s) {
+  UMPR_REQUIRE(g.W % 16 == 0 && ws_bytes >= umpr_conv1_bf16_wgrad_ws_bytes(), "conv1_bf16_wgrad: bad width / workspace");
+  const bf16_t* d0 = static_cast<const bf16_t*>(dy) + g.lead * 8;
+  Wgrad1B16Params p{d0, g.ps, x, ws, g.N, g.H, g.W};
+  {
+    UmprProfScope prof(UMPR_K_B16_WGRAD, 2.0 * (double)g.N * g.H * g.W * 64 * 27, s);
+    conv1_bf16_wgrad_kernel<<<kWgrad1Splits, 256, 0, s>>>(p);
+  }
+  UMPR_LAUNCH_CHECK("conv1_bf16_wgrad");
+  float* bslab = nullptr;
+  if (db) {
+    bslab = ws + (size_t)kWgrad1Splits * 9 * 64 * 3;
+    bias_grad_bf16_kernel<<<dim3(8, kWgrad1Splits), 256, 0, s>>>(d0, g.ps, g.ptot, 64, kWgrad1Splits, bslab);
+    UMPR_LAUNCH_CHECK("bias_grad_bf16");
+  }
+  return umpr_wgrad_reduce(ws, bslab, kWgrad1Splits, 64, 3, dw, db, accumulate, s);
 }

@@ -82,6 +82,10 @@ int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const floa
 size_t umpr_wgrad_bf16_ws_bytes(const UmprPF& g, int Cin, int Cout);
 int umpr_wgrad_bf16_run(const void* dy, const void* x, float* dw, float* db, const UmprPF& g, int Cin, int Cout,
                         int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
+int umpr_conv1_bf16_fwd(const float* x, const float* w, const float* bias, void* y, const UmprPF& g, hipStream_t s);
+size_t umpr_conv1_bf16_wgrad_ws_bytes();
+int umpr_conv1_bf16_wgrad(const void* dy, const float* x, float* dw, float* db, const UmprPF& g, int accumulate, float* ws,
+                          size_t ws_bytes, hipStream_t s);
 int umpr_nchw_to_cb8(const float* x, void* y, const UmprPF& g, int C, hipStream_t s);
 int umpr_cb8_to_nchw(const void* x, float* y, const UmprPF& g, int C, hipStream_t s);
 int umpr_maxpool2_bf16_fwd_run(const void* x, void* y, const UmprPF& gi, const UmprPF& go, int C, hipStream_t s);
