@@ -26,7 +26,7 @@ DP_CHECK = {"proc": None, "log": os.path.join(ROOT, "gpurun_out", "dp_check.log"
 def pytest_sessionstart(session):
     import subprocess
     mexpr = session.config.getoption("-m") or ""
-    if "gpu" not in mexpr or "not gpu" in mexpr or not os.path.exists("/dev/kfd"):
+    if "not gpu" in mexpr or not os.path.exists("/dev/kfd"):   # a GPU box and GPU tests not deselected
         return
     if session.config.getoption("collectonly", False):
         return

@@ -274,7 +274,7 @@ def _reducer_worker(rank, world, port, out):
     model2 = _TinyInPlace()
     opt2 = FusedAdam(model2, 1e-3, 1e-3)
     red2 = parallel.GradReducer(opt2, n_buckets=2)
-    assert len(model2.grad_callbacks) == 1
+    assert red2._written_in_place in model2.grad_callbacks and opt2._on_classifier_grads in model2.grad_callbacks
     for it in range(2):
         opt2.zero_grad()
         model2(x).pow(2).sum().backward()

@@ -12,7 +12,8 @@ done
 python3 - <<'PY'
 import csv, glob, json, os, collections
 R = os.environ['GRAFT_REPO_ROOT']
-fam = lambda n: ('igemm_family' if any(k in n for k in ('conv3x3_igemm', 'wino_', 'pack_weights', 'conv3x3_fwd', 'conv3x3_dgrad'))
+fam = lambda n: ('b16_conv_family' if any(k in n for k in ('conv_bf16_kernel', 'conv1_bf16_fwd'))
+                 else 'igemm_family' if any(k in n for k in ('conv3x3_igemm', 'wino_', 'pack_weights_kernel', 'conv3x3_fwd', 'conv3x3_dgrad'))
                  else 'wgrad_family' if ('wgrad' in n) else None)
 out = collections.defaultdict(lambda: collections.defaultdict(float))
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -30,7 +31,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
             if fam(n):
                 out[fam(n)][c] += float(r['Counter_Value'])
 res = {'steps': 2, 'unit': 'KB (rocprofv3 FETCH_SIZE / WRITE_SIZE raw sums over 2 steps)', 'families': out,
-       'kernels': {k: dict(v, dispatches=calls[k]) for k, v in per_kernel.items() if any(s in k for s in ('conv', 'wino', 'pack'))}}
+       'kernels': {k: dict(v, dispatches=calls[k]) for k, v in per_kernel.items() if any(s in k for s in ('conv', 'wino', 'pack', 'pool', 'cb8'))}}
 json.dump(res, open(R + '/gpurun_out/pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(res['families'], indent=1))
 PY

@@ -280,8 +280,8 @@ size_t vgg_scratch_bytes(int n) {
     const size_t b = umpr_conv3x3_pack_floats(n, L.conv_cin[i], L.conv_cout[i], L.conv_hw[i], L.conv_hw[i]) * sizeof(float);
     if (b > slab) slab = b;
   }
-  size_t fcs = (size_t)4 * n * 25088;
-  if ((size_t)16 * n * 4096 > fcs) fcs = (size_t)16 * n * 4096;
+  size_t fcs = (size_t)16 * n * 25088;
+  if ((size_t)128 * n * 4096 > fcs) fcs = (size_t)128 * n * 4096;
   fcs *= sizeof(float);
   return align_up(slab > fcs ? slab : fcs, 256);
 }

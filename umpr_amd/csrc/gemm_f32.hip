@@ -15,6 +15,7 @@
 #include "umpr_common.h"
 #include "umpr_internal.h"
 #include "umpr_tiles.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -198,8 +199,12 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   if (split <= 0) {  // auto: aim for >= 512 workgroups when K is deep enough to share
     split = 1;
     const long tiles = (long)tm * tn;
-    if (tiles < 256 && g.K >= 512) {
-      split = (int)((512 + tiles - 1) / tiles);
+    // batch-sized M (the VGG classifier at 64 images): the kernel streams a weight matrix once and is bound by memory
+    // latency, not by the MFMA pipe or HBM - more workgroups in flight (3 fit a CU) hide it
+    static const int small_m_target = [] { const char* v = getenv("UMPR_GEMM_SMALL_M_WGS"); return v ? atoi(v) : 512; }();
+    const int target = g.M <= 64 ? small_m_target : 512;
+    if (tiles < target / 2 && g.K >= 512) {
+      split = (int)((target + tiles - 1) / tiles);
       const int maxs = g.K / 128;
       if (split > maxs) split = maxs;
       if (split < 1) split = 1;

@@ -72,6 +72,18 @@ class FusedAdam:
         self.betas = betas
         self.eps = eps
         self.step_count = 0
+        # Early update of the VGG classifier slice (89 % of all parameters): its gradients are final as soon as the
+        # classifier's backward node has run, long before the convolutional backward ends.  When train_step has armed it,
+        # the Adam kernel for that slice runs on a side stream underneath the conv backward (behind the slice's
+        # all-reduce when data parallel) instead of after everything: 0.75 of the 0.85 ms the optimiser takes at batch 64
+        # leaves the critical path.  Elementwise, so the result is bit-identical to the late update.
+        self._early = None          # (grad_scale,) while armed
+        self._early_done = None     # (lo, hi, event) once the slice has been updated in this step
+        self._early_stream = None
+        self.reducer = None         # set by parallel.GradReducer: it then calls early_step after launching its all-reduce
+        for m in model.modules():
+            if hasattr(m, "grad_callbacks"):
+                m.grad_callbacks.append(self._on_classifier_grads)
 
     def zero_grad(self):
         for g in self.groups:
@@ -80,18 +92,64 @@ class FusedAdam:
             for p in g.direct:
                 p._umpr_fresh = True
 
+    def arm_early(self, grad_scale=1.0):
+        """train_step: the coming backward belongs to exactly one optimiser step with this gradient scale."""
+        self._early = (float(grad_scale),)
+        self._early_done = None
+
+    def disarm(self):
+        self._early = None
+
+    def _on_classifier_grads(self):
+        if self._early is not None and self.reducer is None:
+            self.early_step(())
+
+    def early_step(self, handles):
+        """Adam on the classifier-weight slice, on a side stream; `handles`: the slice's pending all-reduces."""
+        if self._early is None or self._early_done is not None:
+            return
+        eb = self.early_bucket()
+        if eb is None or self.groups[0].p.device.type != "cuda":
+            return
+        (scale,) = self._early
+        g = self.groups[0]
+        _, lo, hi, _ = eb
+        dev = g.p.device
+        if self._early_stream is None:
+            self._early_stream = torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        self._early_stream.wait_stream(main)            # the gradients were written on the backward's stream
+        with torch.cuda.stream(self._early_stream):
+            for h in handles:
+                h.wait()                                # orders this stream behind the collective, not the host
+            lib().call("umpr_adam_step", g.p[lo:hi], g.g[lo:hi], g.m[lo:hi], g.v[lo:hi], hi - lo, self.lr, self.betas[0],
+                       self.betas[1], self.eps, g.weight_decay, self.step_count + 1, scale, stream_ptr())
+            ev = torch.cuda.Event()
+            ev.record(self._early_stream)
+        self._early_done = (lo, hi, ev)
+
     def step(self, grad_scale=1.0):
         if self.groups[0].p.device.type != "cuda":
             raise RuntimeError("FusedAdam.step launches a HIP kernel: the model must be on a cuda device")
         self.step_count += 1
-        for g in self.groups:
+        done, self._early_done, self._early = self._early_done, None, None
+        for gi, g in enumerate(self.groups):
             for p in g.direct:
                 if getattr(p, "_umpr_fresh", False):   # no backward node wrote it since zero_grad: its gradient is zero
                     p.grad.zero_()
                     p._umpr_fresh = False
-            if g.numel:
-                lib().call("umpr_adam_step", g.p, g.g, g.m, g.v, g.numel, self.lr, self.betas[0], self.betas[1],
-                           self.eps, g.weight_decay, self.step_count, grad_scale, stream_ptr())
+            if not g.numel:
+                continue
+            ranges = [(0, g.numel)]
+            if gi == 0 and done is not None:           # the classifier slice was updated during backward
+                lo, hi, ev = done
+                ranges = [(0, lo), (hi, g.numel)]
+                torch.cuda.current_stream(g.p.device).wait_event(ev)
+            for lo, hi in ranges:
+                if hi > lo:
+                    lib().call("umpr_adam_step", g.p[lo:hi], g.g[lo:hi], g.m[lo:hi], g.v[lo:hi], hi - lo, self.lr,
+                               self.betas[0], self.betas[1], self.eps, g.weight_decay, self.step_count, grad_scale,
+                               stream_ptr())
 
     def epoch_end(self):
         """ExponentialLR.step() (main.py:54)."""

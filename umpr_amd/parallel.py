@@ -117,6 +117,8 @@ class GradReducer:
         self.fired = False
         self.pending = 0
         self.hooks = []
+        if active() and hasattr(opt, "early_step"):
+            opt.reducer = self     # the optimiser's early classifier update must follow this reducer's all-reduce
         if self.early is not None and active():
             self.pending = len(self.early[3])
             self.hooks = [p.register_post_accumulate_grad_hook(self._landed) for p in self.early[3]]
@@ -138,9 +140,13 @@ class GradReducer:
         if self.fired:
             return
         arena, lo, hi, _ = self.early
+        early = []
         for chunk in torch.chunk(arena[lo:hi], self.n_buckets):
-            self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+            early.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+        self.handles += early
         self.fired = True
+        if hasattr(self.opt, "early_step"):
+            self.opt.early_step(early)   # Adam on the slice, behind its all-reduce, underneath the conv backward
 
     def skip_backward(self):
         """This rank has an empty shard (fewer samples than ranks in the last batch): no backward runs here, so the

@@ -52,6 +52,7 @@ def train_step(model, opt: FusedAdam, batch, world=1, reducer=None):
     pred, loss = model(*batch)
     loss = loss.mean()
     opt.zero_grad()
+    opt.arm_early(1.0 / n_active)    # the classifier slice may be updated as soon as its gradients are final
     loss.backward()
     if world > 1 or reducer is not None:
         if reducer is not None:
