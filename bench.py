@@ -274,6 +274,7 @@ def main():
     for _ in range(args.steps):
         _, loss = step()
         loss_sum += loss.detach()
+    t_issue = time.perf_counter() - t0        # host time to ENQUEUE the steps (no wait): close to dt => host-bound
     barrier()
     dt = time.perf_counter() - t0
     L.fn["umpr_profile_enable"](0)
@@ -380,6 +381,7 @@ def main():
                             ((v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0) if k == "gru" else per_s(v)),
                             "launches_per_step": v[2] / args.steps} for k, v in fam.items() if v[2]},
             "loss_mean": float(loss_sum.item()) / args.steps,
+            "host_issue_ms_per_step": 1e3 * t_issue / args.steps,
         }
         if full:
             gf = 3 * 2 * (TEXT_MMAC_FWD.get(args.emb, 150.6) + args.views * VGG_MMAC_FWD) / 1e3   # GFLOP per sample, training

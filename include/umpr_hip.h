@@ -58,6 +58,17 @@ int umpr_embed_gru_bidir_bwd(const int64_t* ids, const float* emb, int E,
                              float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
                              float* ws, size_t ws_bytes, void* stream);
 
+/* The same with `accumulate` != 0 adding onto the eight gradient buffers instead of overwriting them: the reference uses
+ * ONE GRU for user and item reviews (model.py:45-46) and one for the three C-Net calls (model.py:182-184); a caller that
+ * owns flat gradient storage lets the second and third call accumulate in place instead of adding temporaries. */
+int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E,
+                                 const float* w_hh_f, const float* w_hh_r,
+                                 const int32_t* lengths, const int32_t* order, const int32_t* dst_row, int N, int L,
+                                 const float* dout, const float* out, const float* saved,
+                                 float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
+                                 float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
+                                 int accumulate, float* ws, size_t ws_bytes, void* stream);
+
 /* ---- K4-K5: R-Net co-attention (model.py:50-55) --------------------------------------------------------------
  * Gu, Gi [B][SL][128]; M [128][128].  Outputs soft_u/soft_i [B][SL], atte_u/atte_i rows of 128 written at
  * atte_x + b*ld_x (lets the caller place them inside the [B][256] concat of model.py:166-167).

@@ -25,6 +25,7 @@ SIGNATURES = {
     "umpr_embed_gru_bidir_ws_bytes": ("iii", "z"),
     "umpr_embed_gru_bidir_fwd": ("ppipppppppppppiipppzp", "i"),
     "umpr_embed_gru_bidir_bwd": ("ppipppppiippppppppppppzp", "i"),
+    "umpr_embed_gru_bidir_bwd_acc": ("ppipppppiipppppppppppipzp", "i"),
     "umpr_coattention_fwd_ws_bytes": ("ii", "z"),
     "umpr_coattention_fwd": ("pppiipppplplpppppzp", "i"),
     "umpr_coattention_fwd_bf16": ("pppiipppplplpppppzp", "i"),

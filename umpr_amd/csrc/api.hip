@@ -129,12 +129,12 @@ int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,
   return umpr_gru_recurrent_fwd(gx, w_hh_f, b_hh_f, w_hh_r, b_hh_r, lengths, order, dst_row, out, saved, N, L, S(stream));
 }
 
-int umpr_embed_gru_bidir_bwd(const int64_t* ids, const float* emb, int E, const float* w_hh_f, const float* w_hh_r,
-                             const int32_t* lengths, const int32_t* order, const int32_t* dst_row, int N, int L,
-                             const float* dout, const float* out, const float* saved,
-                             float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
-                             float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
-                             float* ws, size_t ws_bytes, void* stream) {
+int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E, const float* w_hh_f, const float* w_hh_r,
+                                 const int32_t* lengths, const int32_t* order, const int32_t* dst_row, int N, int L,
+                                 const float* dout, const float* out, const float* saved,
+                                 float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
+                                 float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
+                                 int accumulate, float* ws, size_t ws_bytes, void* stream) {
   UMPR_REQUIRE(ws_bytes >= umpr_embed_gru_bidir_ws_bytes(N, L, E), "embed_gru_bwd: workspace too small");
   const int tiles = umpr_gru_tiles(N);
   float* dgx = ws;
@@ -148,16 +148,27 @@ int umpr_embed_gru_bidir_bwd(const int64_t* ids, const float* emb, int E, const 
   float* dbhh[2] = {db_hh_f, db_hh_r};
   float* dwih[2] = {dw_ih_f, dw_ih_r};
   for (int d = 0; d < 2; ++d) {
-    if (int rc = umpr_colsum_rows(wslab + (size_t)d * G3 * H, tiles, G3 * H, 2 * G3 * H, dwhh[d], 0, S(stream))) return rc;
-    if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3, tiles, G3, 4 * G3, dbih[d], 0, S(stream))) return rc;
-    if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3 + G3, tiles, G3, 4 * G3, dbhh[d], 0, S(stream))) return rc;
+    if (int rc = umpr_colsum_rows(wslab + (size_t)d * G3 * H, tiles, G3 * H, 2 * G3 * H, dwhh[d], accumulate, S(stream))) return rc;
+    if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3, tiles, G3, 4 * G3, dbih[d], accumulate, S(stream))) return rc;
+    if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3 + G3, tiles, G3, 4 * G3, dbhh[d], accumulate, S(stream))) return rc;
     UmprGemm g;  // dW_ih[192][E] = dgx[:, d]^T emb[ids]
     g.A = dgx + d * G3; g.lda = 384; g.transA = true; g.B = emb; g.ldb = E; g.gatherB = ids;
     g.C = dwih[d]; g.ldc = E; g.M = G3; g.N = E; g.K = N * L; g.split_k = 0; g.ws = kslab;
     g.ws_bytes = (size_t)128 * G3 * E * sizeof(float);
+    g.accumulate = accumulate != 0;
     if (int rc = umpr_gemm(g, S(stream))) return rc;
   }
   return 0;
+}
+
+int umpr_embed_gru_bidir_bwd(const int64_t* ids, const float* emb, int E, const float* w_hh_f, const float* w_hh_r,
+                             const int32_t* lengths, const int32_t* order, const int32_t* dst_row, int N, int L,
+                             const float* dout, const float* out, const float* saved,
+                             float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
+                             float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
+                             float* ws, size_t ws_bytes, void* stream) {
+  return umpr_embed_gru_bidir_bwd_acc(ids, emb, E, w_hh_f, w_hh_r, lengths, order, dst_row, N, L, dout, out, saved, dw_ih_f,
+                                      dw_hh_f, db_ih_f, db_hh_f, dw_ih_r, dw_hh_r, db_ih_r, db_hh_r, 0, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ co-attention

@@ -34,6 +34,35 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _grad_targets(params, can_accumulate=False):
+    """Where a backward node writes each parameter gradient: straight into ``p.grad`` (a view of FusedAdam's flat
+    arena) when the optimiser marked it fresh in ``zero_grad()`` - no zero fill, no temporary, no accumulate kernel -
+    else into a new tensor that autograd accumulates as usual (second backward without zero_grad, plain optimisers).
+    ``can_accumulate``: the kernel can ADD onto existing gradients, so a parameter another node already wrote in this
+    step (shared weights: one GRU serves several review tensors) is also updated in place.  Returns (targets, direct,
+    accumulate) with ``accumulate`` true when the kernel must add; all parameters of a call share one mode."""
+    def usable(p):
+        g = p.grad
+        return (g is not None and getattr(p, "_umpr_direct", False) and g.is_contiguous() and g.shape == p.shape
+                and g.device == p.device and g.dtype == torch.float32)
+    fresh = [usable(p) and getattr(p, "_umpr_fresh", False) for p in params]
+    written = [usable(p) and getattr(p, "_umpr_written", False) and not getattr(p, "_umpr_fresh", False) for p in params]
+    if can_accumulate and params and all(written):
+        return [p.grad for p in params], [True] * len(params), True
+    if can_accumulate and not all(fresh):
+        fresh = [False] * len(params)          # mixed state: let autograd accumulate everything
+    dst = [p.grad if ok else torch.empty_like(p) for p, ok in zip(params, fresh)]
+    return (dst, fresh, False) if can_accumulate else (dst, fresh)
+
+
+def _grad_returns(params, dst, direct):
+    for p, d in zip(params, direct):
+        if d:
+            p._umpr_fresh = False
+            p._umpr_written = True    # holds this step's gradient: a later node of the same step may add in place
+    return [None if d else g for g, d in zip(dst, direct)]
+
+
 # --------------------------------------------------------------------------------------------- K1-K3
 class _EmbedGru(torch.autograd.Function):
     """nn.Embedding + ImprovedRnn(nn.GRU bidirectional) (src/model.py:262-264, 12-21)."""
@@ -46,6 +75,7 @@ class _EmbedGru(torch.autograd.Function):
         out = torch.empty(N, L, D, device=ids.device, dtype=torch.float32)
         saved = torch.empty(2, N, L, 4, H, device=ids.device, dtype=torch.float32) if need else None
         ws, wsb = _ws(lib().size("umpr_embed_gru_bidir_ws_bytes", N, L, E), ids.device)
+        ctx.param_objs = w
         w = [_c(x) for x in w]
         lib().call("umpr_embed_gru_bidir_fwd", ids, emb, E, *w, lengths, order, order, N, L, out, saved, ws, wsb,
                    stream_ptr())
@@ -59,13 +89,13 @@ class _EmbedGru(torch.autograd.Function):
         N, L = ids.shape
         E = emb.shape[1]
         dev = ids.device
-        g = [torch.empty(3 * H, E, device=dev), torch.empty(3 * H, H, device=dev), torch.empty(3 * H, device=dev),
-             torch.empty(3 * H, device=dev), torch.empty(3 * H, E, device=dev), torch.empty(3 * H, H, device=dev),
-             torch.empty(3 * H, device=dev), torch.empty(3 * H, device=dev)]
+        # the reference shares one GRU between the user and item reviews (and one between the three C-Net calls): the first
+        # backward of a step overwrites the gradient slices of the optimiser's arena, the later ones add in place
+        g, direct, acc = _grad_targets(ctx.param_objs, can_accumulate=True)
         ws, wsb = _ws(lib().size("umpr_embed_gru_bidir_ws_bytes", N, L, E), dev)
-        lib().call("umpr_embed_gru_bidir_bwd", ids, emb, E, whh_f, whh_r, lengths, order, order, N, L, _c(dout), out,
-                   saved, *g, ws, wsb, stream_ptr())
-        return (None, None, None, None, *g)
+        lib().call("umpr_embed_gru_bidir_bwd_acc", ids, emb, E, whh_f, whh_r, lengths, order, order, N, L, _c(dout), out,
+                   saved, *g, int(acc), ws, wsb, stream_ptr())
+        return (None, None, None, None, *_grad_returns(ctx.param_objs, g, direct))
 
 
 # --------------------------------------------------------------------------------------------- K4-K7
@@ -77,6 +107,7 @@ class _ReviewHead(torch.autograd.Function):
         B, SL, _ = gru_u.shape
         dev = gru_u.device
         f = dict(device=dev, dtype=torch.float32)
+        ctx.param_objs = (M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i)
         gru_u, gru_i = _c(gru_u), _c(gru_i)
         T = torch.empty(B, SL, D, **f)
         soft_u, soft_i = torch.empty(B, SL, **f), torch.empty(B, SL, **f)
@@ -113,25 +144,26 @@ class _ReviewHead(torch.autograd.Function):
         f = dict(device=dev, dtype=torch.float32)
         st = stream_ptr()
         d_repr_u, d_repr_i = torch.empty(B, 2 * D, **f), torch.empty(B, 2 * D, **f)
-        dW_u, dW_i = torch.empty_like(W_u), torch.empty_like(W_i)
+        tg, direct = _grad_targets(ctx.param_objs)    # (M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i): each used once per step
+        dW_u, dW_i = tg[5], tg[6]
         ws, wsb = _ws(lib().size("umpr_review_merge_bwd_ws_bytes", B), dev)
         lib().call("umpr_review_merge_bwd", repr_u, repr_i, W_u, W_i, out, _c(d_out), B, d_repr_u, d_repr_i, dW_u, dW_i,
                    ws, wsb, st)
         dG, dMs, dWs, dsoft = [], [], [], []
         ws, wsb = _ws(lib().size("umpr_snet_bwd_ws_bytes", B, S, L), dev)
-        for X, Ms, Ws, U, P, wsum, sa, drep in ((gru_u, Ms_u, Ws_u, U_u, P_u, wsum_u, sa_u, d_repr_u),
-                                                (gru_i, Ms_i, Ws_i, U_i, P_i, wsum_i, sa_i, d_repr_i)):
+        for X, Ms, Ws, U, P, wsum, sa, drep, gMs, gWs in ((gru_u, Ms_u, Ws_u, U_u, P_u, wsum_u, sa_u, d_repr_u, tg[1], tg[2]),
+                                                          (gru_i, Ms_i, Ws_i, U_i, P_i, wsum_i, sa_i, d_repr_i, tg[3], tg[4])):
             dX = torch.empty(B, SL, D, **f)
-            gMs, gWs = torch.empty_like(Ms), torch.empty_like(Ws)
             ds = torch.empty(B, SL, **f)
             lib().call("umpr_snet_bwd", X, Ms, Ws, U, P, wsum, sa, drep.data_ptr() + D * 4, 2 * D, None, B, S, L, L, dX,
                        gMs, gWs, ds, ws, wsb, st)
             dG.append(dX); dMs.append(gMs); dWs.append(gWs); dsoft.append(ds)
-        dM = torch.empty_like(M)
+        dM = tg[0]
         ws, wsb = _ws(lib().size("umpr_coattention_bwd_ws_bytes", B, SL), dev)
         lib().call("umpr_coattention_bwd", gru_u, gru_i, M, T, soft_u, soft_i, colmax, argcol, rowmax, argrow,
                    d_repr_u, 2 * D, d_repr_i, 2 * D, dsoft[0], dsoft[1], B, SL, dG[0], dG[1], dM, 1, ws, wsb, st)
-        return dG[0], dG[1], None, None, dM, dMs[0], dWs[0], dMs[1], dWs[1], dW_u, dW_i, None
+        ret = _grad_returns(ctx.param_objs, tg, direct)
+        return (dG[0], dG[1], None, None, *ret, None)
 
 
 # --------------------------------------------------------------------------------------------- K8-K9
@@ -146,6 +178,7 @@ class _Control(torch.autograd.Function):
         dev = g_ui.device
         f = dict(device=dev, dtype=torch.float32)
         st = stream_ptr()
+        ctx.param_objs = (Wc, bc, Wl, bl, Ms, Ws, ssW, ssb)
         g_ui, g_u, g_i = _c(g_ui), _c(g_u), _c(g_i)
         saved = []
         finals = []
@@ -192,17 +225,17 @@ class _Control(torch.autograd.Function):
         d_sa = torch.empty(B, S_ui, D, **f)
         d_vp = torch.empty(B, S_ui, V, **f)
         d_cout = torch.empty(B, V, **f)
-        dssW, dssb = torch.empty_like(ssW), torch.empty(1, **f)
+        tg, direct = _grad_targets(ctx.param_objs)    # (Wc, bc, Wl, bl, Ms, Ws, ssW, ssb): this node is their only writer
+        dssW, dssb = tg[6], tg[7]
         ws, wsb = _ws(lib().size("umpr_control_gate_bwd_ws_bytes", B), dev)
         lib().call("umpr_control_gate_bwd", sa, ssW, view_p, c_out, senti, vs, d_pp, d_pn, B, S_ui, V, d_sa, d_vp,
                    d_cout, dssW, dssb, ws, wsb, st)
         dX_ui = torch.empty(B, S_ui * L_ui, D, **f)
-        dMs, dWs = torch.empty_like(Ms), torch.empty_like(Ws)
+        dMs, dWs = tg[4], tg[5]
         ws, wsb = _ws(lib().size("umpr_snet_bwd_ws_bytes", B, S_ui, L_ui), dev)
         lib().call("umpr_snet_bwd", g_ui, Ms, Ws, U, P, wsum, sa, zeros(B, D), D, d_sa, B, S_ui, L_ui, V, dX_ui, dMs,
                    dWs, None, ws, wsb, st)
-        dWc, dbc = torch.empty_like(Wc), torch.empty(KC, **f)
-        dWl, dbl = torch.empty_like(Wl), torch.empty(V, **f)
+        dWc, dbc, dWl, dbl = tg[0], tg[1], tg[2], tg[3]
         dX_u, dX_i = torch.empty(B, S * L, D, **f), torch.empty(B, S * L, D, **f)
         calls = ((g_ui, S_ui, L_ui, saved[0:4], d_cout, d_vp, dX_ui, 1, 0),
                  (g_u, S, L, saved[4:8], d_cu, None, dX_u, 0, 1),
@@ -211,31 +244,11 @@ class _Control(torch.autograd.Function):
             ws, wsb = _ws(lib().size("umpr_cnet_head_bwd_ws_bytes", B, s, l, KC, KS, V), dev)
             lib().call("umpr_cnet_head_bwd", X, Wc, Wl, cmax, argl, sp, vp, dfin, dvp, B, s, l, KC, KS, V, dX, accx,
                        accw, dWc, dbc, dWl, dbl, ws, wsb, st)
-        return dX_ui, dX_u, dX_i, None, None, dWc, dbc, dWl, dbl, dMs, dWs, dssW, dssb.reshape(1)
+        ret = _grad_returns(ctx.param_objs, tg, direct)
+        return (dX_ui, dX_u, dX_i, None, None, *ret)
 
 
 # --------------------------------------------------------------------------------------------- K10
-def _grad_targets(params):
-    """Where a backward node writes each parameter gradient: straight into ``p.grad`` (a view of FusedAdam's flat
-    arena) when the optimiser marked it fresh in ``zero_grad()`` - no zero fill, no temporary, no accumulate kernel -
-    else into a new tensor that autograd accumulates as usual (second backward without zero_grad, plain optimisers)."""
-    dst, direct = [], []
-    for p in params:
-        g = p.grad
-        ok = (g is not None and getattr(p, "_umpr_fresh", False) and g.is_contiguous() and g.shape == p.shape
-              and g.device == p.device and g.dtype == torch.float32)
-        dst.append(g if ok else torch.empty_like(p))
-        direct.append(ok)
-    return dst, direct
-
-
-def _grad_returns(params, dst, direct):
-    for p, d in zip(params, direct):
-        if d:
-            p._umpr_fresh = False
-    return [None if d else g for g, d in zip(dst, direct)]
-
-
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return arr, ctypes.cast(arr, ctypes.c_void_p)
@@ -572,6 +585,13 @@ class UMPR(nn.Module):
                                         dtype=self.compute_dtype)
             self.linear_fusion = nn.Sequential(nn.Linear(config.gru_size * 2 + view_size + view_size, 1), nn.ReLU())
         self.last_loss_terms = None
+        # Parameters whose backward node can write the gradient straight into the optimiser's arena (_grad_targets):
+        # everything in the review / control nets (GRU weights accumulate in place across their uses) and, set by VGG16
+        # itself, the VGG stack.  The head's parameters keep autograd's accumulation.
+        for mod in (self.review_net, getattr(self, "control_net", None)):
+            if mod is not None:
+                for p in mod.parameters():
+                    p._umpr_direct = True
 
     @staticmethod
     def _host_perm(lengths, device):
