@@ -12,6 +12,38 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 sel = [r for r in rows if any(k in r['Kernel_Name'] for k in ('gemm_f32', 'splitk_reduce', 'colsum', 'wgrad_reduce'))]
 sel.sort(key=lambda r: int(r['End_Timestamp']) - int(r['Start_Timestamp']), reverse=True)
+# per-queue (stream) busy time: which stream is the critical path
+hdr = rows[0].keys()
+qk = 'Queue_Id' if 'Queue_Id' in hdr else ('Stream_Id' if 'Stream_Id' in hdr else None)
+if qk:
+    t0 = min(int(r['Start_Timestamp']) for r in rows); t1 = max(int(r['End_Timestamp']) for r in rows)
+    half = (t0 + t1) // 2                      # second half of the run = steady-state steps
+    per = collections.defaultdict(lambda: [0, 0, None, None])
+    for r in rows:
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        if s < half: continue
+        q = per[r[qk]]
+        q[0] += e - s; q[1] += 1
+        q[2] = s if q[2] is None else min(q[2], s); q[3] = e if q[3] is None else max(q[3], e)
+    print(f"per-{qk} busy time in the second half of the trace ({(t1 - half)/1e6:.2f} ms):")
+    for k, v in sorted(per.items(), key=lambda kv: -kv[1][0]):
+        print(f"  {qk} {k}: busy {v[0]/1e6:7.2f} ms in {v[1]:5d} dispatches, span {(v[3]-v[2])/1e6:7.2f} ms")
+    # idle gaps > 40 us on the busiest queue inside the last step of the trace (between which kernels does it wait?)
+    mainq = max(per.items(), key=lambda kv: kv[1][0])[0]
+    mq = sorted((r for r in rows if r[qk] == mainq), key=lambda r: int(r['Start_Timestamp']))
+    adam = [i for i, r in enumerate(mq) if 'adam_kernel' in r['Kernel_Name']]
+    if len(adam) >= 2:
+        lo = max(i for i in adam if i < adam[-1] - 20) if any(i < adam[-1] - 20 for i in adam) else 0
+        seg = mq[lo:adam[-1] + 1]
+        print(f"queue {mainq}: last step = {len(seg)} dispatches, {(int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp']))/1e6:.2f} ms; gaps > 40 us:")
+        sh = lambda r: r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:44]
+        tot = 0
+        for a, b in zip(seg, seg[1:]):
+            gap = int(b['Start_Timestamp']) - int(a['End_Timestamp'])
+            if gap > 0: tot += gap
+            if gap > 40000:
+                print(f"   {gap/1e3:8.1f} us  after {sh(a)}  before {sh(b)}")
+        print(f"   total idle between kernels on that queue: {tot/1e6:.2f} ms")
 print("longest generic-kernel dispatches:")
 for r in sel[:24]:
     n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:60]

@@ -107,8 +107,9 @@ int umpr_gemm_f32(const float* A, long lda, int transA, const float* B, long ldb
 // ------------------------------------------------------------------------------------------------ GRU
 size_t umpr_embed_gru_bidir_ws_bytes(int N, int L, int E) {
   const size_t tiles = umpr_gru_tiles(N);
-  // gx / dgx [N*L*384] + dWhh slabs + bias slabs + split-K slab for dW_ih
-  return ((size_t)N * L * 384 + tiles * 2 * G3 * H + tiles * 2 * 2 * G3 + (size_t)128 * G3 * E) * sizeof(float);
+  // gx / dgx [N*L*384] + dWhh slabs + bias slabs + split-K slab for dW_ih (forward: the stacked input weights) + the
+  // stacked [384][E] weight gradient
+  return ((size_t)N * L * 384 + tiles * 2 * G3 * H + tiles * 2 * 2 * G3 + (size_t)128 * G3 * E + (size_t)2 * G3 * E) * sizeof(float);
 }
 
 int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,
@@ -119,12 +120,32 @@ int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,
   UMPR_REQUIRE(N > 0 && L > 0 && E > 0, "embed_gru: bad shape N=%d L=%d E=%d", N, L, E);
   UMPR_REQUIRE(ws_bytes >= (size_t)N * L * 384 * sizeof(float), "embed_gru: workspace too small");
   float* gx = ws;
-  for (int d = 0; d < 2; ++d) {  // gx[:, d*192:(d+1)*192] = emb[ids] W_ih^T + b_ih
+  // gx[:, 0:192 | 192:384] = emb[ids] [W_ih_f ; W_ih_r]^T + [b_ih_f ; b_ih_r]: ONE gather-GEMM for both directions (the
+  // embedding rows are fetched once instead of twice, and N = 384 fills three 128-column tiles where 192 wasted half of
+  // its second one).  The stacked [384][E] weight / [384] bias live behind gx in the workspace.
+  if (ws_bytes >= umpr_embed_gru_bidir_ws_bytes(N, L, E)) {
+    float* wst = gx + (size_t)N * L * 384 + (size_t)umpr_gru_tiles(N) * (2 * G3 * H + 2 * 2 * G3);   // the dW_ih slab area
+    float* bst = wst + (size_t)2 * G3 * E;
+    const hipStream_t s = S(stream);
+    if (hipMemcpyAsync(wst, w_ih_f, (size_t)G3 * E * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(wst + (size_t)G3 * E, w_ih_r, (size_t)G3 * E * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(bst, b_ih_f, G3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(bst + G3, b_ih_r, G3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      umpr_set_error("embed_gru: stacking the input weights failed");
+      return -2;
+    }
     UmprGemm g;
-    g.A = emb; g.lda = E; g.gatherA = ids; g.B = d ? w_ih_r : w_ih_f; g.ldb = E; g.transB = true;
-    g.C = gx + d * G3; g.ldc = 384; g.M = N * L; g.N = G3; g.K = E;
-    g.bias = d ? b_ih_r : b_ih_f; g.bias_mode = 1;
-    if (int rc = umpr_gemm(g, S(stream))) return rc;
+    g.A = emb; g.lda = E; g.gatherA = ids; g.B = wst; g.ldb = E; g.transB = true;
+    g.C = gx; g.ldc = 384; g.M = N * L; g.N = 2 * G3; g.K = E; g.bias = bst; g.bias_mode = 1;
+    if (int rc = umpr_gemm(g, s)) return rc;
+  } else {
+    for (int d = 0; d < 2; ++d) {  // small workspace (inference callers sized for gx only): one GEMM per direction
+      UmprGemm g;
+      g.A = emb; g.lda = E; g.gatherA = ids; g.B = d ? w_ih_r : w_ih_f; g.ldb = E; g.transB = true;
+      g.C = gx + d * G3; g.ldc = 384; g.M = N * L; g.N = G3; g.K = E;
+      g.bias = d ? b_ih_r : b_ih_f; g.bias_mode = 1;
+      if (int rc = umpr_gemm(g, S(stream))) return rc;
+    }
   }
   return umpr_gru_recurrent_fwd(gx, w_hh_f, b_hh_f, w_hh_r, b_hh_r, lengths, order, dst_row, out, saved, N, L, S(stream));
 }
@@ -151,12 +172,17 @@ int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E, co
     if (int rc = umpr_colsum_rows(wslab + (size_t)d * G3 * H, tiles, G3 * H, 2 * G3 * H, dwhh[d], accumulate, S(stream))) return rc;
     if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3, tiles, G3, 4 * G3, dbih[d], accumulate, S(stream))) return rc;
     if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3 + G3, tiles, G3, 4 * G3, dbhh[d], accumulate, S(stream))) return rc;
-    UmprGemm g;  // dW_ih[192][E] = dgx[:, d]^T emb[ids]
-    g.A = dgx + d * G3; g.lda = 384; g.transA = true; g.B = emb; g.ldb = E; g.gatherB = ids;
-    g.C = dwih[d]; g.ldc = E; g.M = G3; g.N = E; g.K = N * L; g.split_k = 0; g.ws = kslab;
+  }
+  {  // [dW_ih_f ; dW_ih_r] [384][E] = dgx^T emb[ids]: one split-K gather-GEMM for both directions, then rows 0..191 /
+     // 192..383 are copied (or added) to their parameters' gradients
+    float* stacked = kslab + (size_t)128 * G3 * E;
+    UmprGemm g;
+    g.A = dgx; g.lda = 384; g.transA = true; g.B = emb; g.ldb = E; g.gatherB = ids;
+    g.C = stacked; g.ldc = E; g.M = 2 * G3; g.N = E; g.K = N * L; g.split_k = 0; g.ws = kslab;
     g.ws_bytes = (size_t)128 * G3 * E * sizeof(float);
-    g.accumulate = accumulate != 0;
     if (int rc = umpr_gemm(g, S(stream))) return rc;
+    if (int rc = umpr_copy_or_add(stacked, dwih[0], (long)G3 * E, accumulate, S(stream))) return rc;
+    if (int rc = umpr_copy_or_add(stacked + (size_t)G3 * E, dwih[1], (long)G3 * E, accumulate, S(stream))) return rc;
   }
   return 0;
 }
@@ -674,19 +700,25 @@ int umpr_vgg16_bf16_features_fwd(const float* images, const float* const* params
   const VggB16Layout L = vgg_b16_layout(n);
   hipStream_t s = S(stream);
   void* wpack = ws;
+  {  // the zero guards of all 18 activation tensors in one launch
+    void* bases[18]; UmprPF geos[18]; int ch[18];
+    for (int i = 0; i < 13; ++i) { bases[i] = BP(acts) + L.conv_off[i]; geos[i] = L.geo[L.conv_block[i]]; ch[i] = L.conv_cout[i]; }
+    for (int b = 0; b < 5; ++b) { bases[13 + b] = BP(acts) + L.pool_off[b]; geos[13 + b] = L.pool_geo[b]; ch[13 + b] = kBlockCh[b]; }
+    if (int rc = umpr_pf_zero_guards_multi(bases, geos, ch, 18, s)) return rc;
+  }
   // first layer (3 input channels, K = 27 padded to 32): its own kernel, fp32 image in, bf16 CB8-PF out
-  if (int rc = umpr_conv1_bf16_fwd(images, params[0], params[1], BP(acts) + L.conv_off[0], L.geo[0], s)) return rc;
+  if (int rc = umpr_conv1_bf16_fwd(images, params[0], params[1], BP(acts) + L.conv_off[0], L.geo[0], s, false)) return rc;
   const void* x = BP(acts) + L.conv_off[0];
   int ci = 1;
   for (int b = 0; b < 5; ++b) {
     for (int j = (b == 0 ? 1 : 0); j < kConvPerBlock[b]; ++j, ++ci) {
       void* y = BP(acts) + L.conv_off[ci];
       if (int rc = umpr_conv_bf16_run(x, params[2 * ci], 0, params[2 * ci + 1], nullptr, y, L.geo[b], L.conv_cin[ci],
-                                      L.conv_cout[ci], 1, wpack, b16_pack_bytes(), s)) return rc;
+                                      L.conv_cout[ci], 1, wpack, b16_pack_bytes(), s, false)) return rc;
       x = y;
     }
     void* y = BP(acts) + L.pool_off[b];
-    if (int rc = umpr_maxpool2_bf16_fwd_run(x, y, L.geo[b], L.pool_geo[b], kBlockCh[b], s)) return rc;
+    if (int rc = umpr_maxpool2_bf16_fwd_run(x, y, L.geo[b], L.pool_geo[b], kBlockCh[b], s, false)) return rc;
     x = y;
   }
   return umpr_cb8_to_nchw(x, pool5, L.pool_geo[4], 512, s);

@@ -82,7 +82,9 @@ struct ConvB16Params {
 
 // W: map width.  TR > 0: 2-D tile of TR rows x TC real columns; TR == 0: 1-D tile of TC consecutive flat pixels.
 // BN output channels per workgroup; WP x WC waves (pixels x channels).
-template <int W, int TR, int TC, int BN, int WP, int WC>
+// ABL (ablation builds for timing only, results wrong): 1 = no per-step vmcnt wait / barrier, 2 = fragments read once,
+// 3 = no DMA in the loop
+template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3, int ABL = 0>
 __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf16_kernel(ConvB16Params p) {
   constexpr int NW = WP * WC, NT = 64 * NW;
   constexpr bool TWO_D = TR > 0;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
   constexpr int PPW = (PPC + NW - 1) / NW;        // ... per wave (surplus slots repeat a piece)
   constexpr int WPS = BN / 16;                    // weight pieces per step (BN x 64 B)
   constexpr int WPW = (WPS + NW - 1) / NW;
-  constexpr int D = 3, NB = D + 1;                // weights arrive D steps ahead in a ring of NB stages
+  constexpr int NB = D + 1;                       // weights arrive D steps ahead in a ring of NB stages
   constexpr int TPW = BM / WP / 32, TCW = BN / WC / 32;
   constexpr int WB = BN * 32, PB = 4 * PPX * 8;   // elements per weight stage / patch stage
   static_assert(BM % (32 * WP) == 0 && BN % (32 * WC) == 0 && (!TWO_D || (W % TC == 0 && TC % 16 == 0)), "tile shape");
@@ -204,18 +206,27 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int s = c * 9 + t;
-      issue_w(s + D);
-      if (t == 0) issue_p(c + 1);
+      if (ABL != 3) {
+        issue_w(s + D);
+        if (t == 0) issue_p(c + 1);
+      }
       const char* wb = reinterpret_cast<const char*>(Wb) + (s % NB) * (WB * 2);
       constexpr int dummy = 0; (void)dummy;
       const int toff = ((t / 3) - 1) * TS + (t % 3) - 1;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 a[TCW], b[TPW];
+        if (ABL == 2) {
+#pragma unroll
+          for (int i = 0; i < TCW; ++i) { a[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Wb) + wbo + i * 512); asm volatile("" : "+v"(a[i])); }
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) { b[j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Pb) + pbo[j]); asm volatile("" : "+v"(b[j])); }
+        } else {
 #pragma unroll
         for (int i = 0; i < TCW; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wb + wbo + (ks * 2 * BN + i * 32) * 16);
 #pragma unroll
         for (int j = 0; j < TPW; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pb + pbo[j] + (ks * 2 * PPX + toff) * 16);
+        }
 #pragma unroll
         for (int i = 0; i < TCW; ++i)
 #pragma unroll
@@ -223,8 +234,10 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
       }
       // stage s+1 (and, from the fourth step of a chunk on, the next chunk's patch) must have landed; the younger DMAs
       // (D-1 weight stages, plus the patch while it may still fly) stay in flight across the barrier
-      if (t < D) wait_vm<(D - 1) * WPW + PPW>(); else wait_vm<(D - 1) * WPW>();
-      __syncthreads();
+      if (ABL != 1 && ABL != 3) {
+        if (t < D) wait_vm<(D - 1) * WPW + PPW>(); else wait_vm<(D - 1) * WPW>();
+      }
+      if (ABL != 1) __syncthreads();
     }
   }
   wait_vm<0>();
@@ -315,7 +328,8 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, bf16_t* __
 struct WgradB16Params {
   const bf16_t* dy; long dps;    // [Cout/8][ps][8], zero at pads and in the guards
   const bf16_t* x; long xps;     // [Cin/8][ps][8]
-  float* slab;                   // [splits][9][Cout][Cin]
+  float* slab;                   // [splits][Cout][Cin][9]: the parameter's own order, summed by the linear reduce
+  float* bslab;                  // [splits][Cout] bias-gradient partial sums (written by the ci-tile-0 workgroups) or null
   int Cin, Cout;
   long nseg;                     // pixel segments
   int segs_per_split, splits, ntiles, ncit;
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * KSW) void wgrad_bf16_kernel(WgradB
   constexpr int GB = GPL * KPX * 8, XB = XPL * PPX * 8;   // elements per stage
   constexpr int KSTEPS = KP / 16, KSL = KSTEPS / KSW;
   static_assert(KP % 64 == 0 && KSTEPS % KSW == 0 && (!TWO_D || (W % TC == 0 && TC % 16 == 0)), "segment shape");
-  constexpr int RED = KSW > 1 ? WCO * WCI * 9 * 16 * 64 * 2 : 0;   // fp32 exchange of the wave groups, in bf16 units
+  constexpr int RED = KSW > 1 ? (WCO * WCI * 9 * 16 * 64 + WCO * WCI * 32) * 2 : 0;   // fp32 exchange of the wave groups, in bf16 units
   constexpr int SMEM = 2 * (GB + XB) > RED ? 2 * (GB + XB) : RED;
   __shared__ __attribute__((aligned(1024))) bf16_t smem[SMEM];
   bf16_t* const Gs = smem;                         // [2][GB]
@@ -422,6 +436,10 @@ __global__ __launch_bounds__(64 * WCO * WCI * KSW) void wgrad_bf16_kernel(WgradB
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int x = 0; x < 16; ++x) acc[t][x] = 0.f;
+  // bias gradient: the A fragment of a lane is 8 pixels of ONE output channel (row l & 31 of the wave's 32) - the waves
+  // with input-channel position 0 of the ci-tile-0 workgroups add them up on the side (16 VALU per 9 MFMAs)
+  const bool do_bias = p.bslab != nullptr && cit == 0 && wci == 0;   // wave-uniform
+  float bsum = 0.f;
 
   if (sbeg < send) issue(sbeg, 0);
   wait_vm<0>();
@@ -443,6 +461,12 @@ __global__ __launch_bounds__(64 * WCO * WCI * KSW) void wgrad_bf16_kernel(WgradB
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a[e] = a0[e]; a[4 + e] = a1[e]; }
       }
+      if (do_bias) {
+        float s4 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s4 += (float)a[e];
+        bsum += s4;
+      }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int toff = ((t / 3) - 1) * TS + (t % 3) - 1;
@@ -459,13 +483,15 @@ __global__ __launch_bounds__(64 * WCO * WCI * KSW) void wgrad_bf16_kernel(WgradB
   }
 
   // ---- combine the KSW wave groups through LDS, then store the slab tile: D[co][ci], lanes run along ci
+  bsum += __shfl_xor(bsum, 32, 64);                    // the two k-halves of a channel
   if (KSW > 1) {
-    float* red = reinterpret_cast<float*>(smem);       // [WCO*WCI][9][16][64] floats = 36 KB per wave
+    float* red = reinterpret_cast<float*>(smem);       // [WCO*WCI][9][16][64] floats = 36 KB per wave, then [WCO*WCI][32]
     if (ksw == 1) {
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int x = 0; x < 16; ++x) red[((wt * 9 + t) * 16 + x) * 64 + lane] = acc[t][x];
+      if (lane < 32) red[WCO * WCI * 9 * 16 * 64 + wt * 32 + lane] = bsum;
     }
     __syncthreads();
     if (ksw == 0) {
@@ -473,18 +499,48 @@ __global__ __launch_bounds__(64 * WCO * WCI * KSW) void wgrad_bf16_kernel(WgradB
       for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int x = 0; x < 16; ++x) acc[t][x] += red[((wt * 9 + t) * 16 + x) * 64 + lane];
+      bsum += red[WCO * WCI * 9 * 16 * 64 + wt * 32 + (lane & 31)];
     }
   }
   if (ksw == 0) {
     const int r = lane & 31, h = lane >> 5;
     const int ci = cit * 32 * WCI + wci * 32 + r;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int x = 0; x < 16; ++x) {
+      const int co = cot * 32 * WCO + wco * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+      float* o = p.slab + (((long)split * p.Cout + co) * p.Cin + ci) * 9;
 #pragma unroll
-      for (int x = 0; x < 16; ++x) {
-        const int co = cot * 32 * WCO + wco * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-        p.slab[(((long)split * 9 + t) * p.Cout + co) * p.Cin + ci] = acc[t][x];
+      for (int t = 0; t < 9; ++t) o[t] = acc[t][x];
+    }
+    if (do_bias && lane < 32) p.bslab[(long)split * p.Cout + cot * 32 * WCO + wco * 32 + lane] = bsum;
+  }
+}
+
+// dW (+)= sum over splits of slab[split][...] in the parameter's own order (float4), db likewise from bslab
+__global__ void wgrad_reduce_linear_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, int splits,
+                                           long per, int Cout, float* __restrict__ dw, float* __restrict__ db,
+                                           int accumulate) {
+  const long nv = per / 4;                               // per = 9 * Cout * Cin is a multiple of 4 (channels of 64)
+  const float4* s4 = reinterpret_cast<const float4*>(slab);
+  float4* d4 = reinterpret_cast<float4*>(dw);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv + (bslab ? Cout : 0); i += (long)gridDim.x * blockDim.x) {
+    if (i < nv) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;   // two interleaved chains, fixed order
+      int q = 0;
+      for (; q + 1 < splits; q += 2) {
+        const float4 u = s4[(long)q * nv + i], v = s4[(long)(q + 1) * nv + i];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
       }
+      if (q < splits) { const float4 u = s4[(long)q * nv + i]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+      float4 r = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+      if (accumulate) { const float4 o = d4[i]; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+      d4[i] = r;
+    } else {
+      const int co = (int)(i - nv);
+      float v = 0.f;
+      for (int q = 0; q < splits; ++q) v += bslab[(long)q * Cout + co];
+      db[co] = accumulate ? db[co] + v : v;
+    }
   }
 }
 
@@ -570,6 +626,20 @@ __global__ void zero_guards_kernel(bf16_t* __restrict__ base, long ps, long lead
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long P = i < lead ? i : tail0 + (i - lead);
     *reinterpret_cast<uint4*>(base + ((long)pl * ps + P) * 8) = z;
+  }
+}
+
+// the same for up to 20 tensors in one launch (the activation arena of a forward pass): blockIdx.y = tensor
+struct GuardSet { bf16_t* base[20]; long ps[20], lead[20], ptot[20]; int planes[20]; int n; };
+__global__ void zero_guards_multi_kernel(GuardSet gs) {
+  const int t = blockIdx.y;
+  const long ps = gs.ps[t], lead = gs.lead[t], tail0 = lead + gs.ptot[t];
+  const long per = lead + (ps - tail0), n = per * gs.planes[t];
+  uint4 z = make_uint4(0, 0, 0, 0);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long pl = i / per, q = i - pl * per;
+    const long P = q < lead ? q : tail0 + (q - lead);
+    *reinterpret_cast<uint4*>(gs.base[t] + (pl * ps + P) * 8) = z;
   }
 }
 
@@ -727,10 +797,12 @@ __global__ void pf_zero_pads_kernel(bf16_t* __restrict__ y, long yps, int H, int
 // 16 along a row.  Both fragments are gathered straight from memory (each dY element exactly once in the whole launch, the
 // image from L2): no LDS in the loop; the waves of a workgroup are summed through LDS at the end, workgroups write
 // split-K slabs [split][9][64][3] for the shared reduce kernel.
-struct Wgrad1B16Params { const bf16_t* dy; long dps; const float* x; float* slab; int N, H, W; };
+struct Wgrad1B16Params { const bf16_t* dy; long dps; const float* x; float* slab; float* bslab; int N, H, W; };
 
 __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(Wgrad1B16Params p) {
   __shared__ float red[3][2][16][64];
+  __shared__ float bred[4][64];
+  float bs[2] = {0.f, 0.f};
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
   const long wave = (long)blockIdx.x * 4 + wv, nwaves = (long)gridDim.x * 4;
   const int H = p.H, W = p.W, RW = W + 1;
@@ -760,6 +832,10 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(Wgrad1B16Params p
       const bf16_t* g = p.dy + ((long)(co >> 3) * p.dps + P) * 8 + (co & 7);
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[i][j] = g[j * 8];
+      float s8 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s8 += (float)a[i][j];
+      bs[i] += s8;                                               // bias gradient of channel i*32 + r on the side
     }
     // B[k = pixel][col = (c, tap)]: the image at (y + dy, x0 + j + dx), zero outside
     bf16x8 b;
@@ -782,7 +858,12 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(Wgrad1B16Params p
 #pragma unroll
       for (int x = 0; x < 16; ++x) red[wv - 1][i][x][lane] = acc[i][x];
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) bs[i] += __shfl_xor(bs[i], 32, 64);
+  if (lane < 32) { bred[wv][lane] = bs[0]; bred[wv][32 + lane] = bs[1]; }
   __syncthreads();
+  if (p.bslab && threadIdx.x < 64)
+    p.bslab[(long)blockIdx.x * 64 + threadIdx.x] = (bred[0][threadIdx.x] + bred[1][threadIdx.x]) + (bred[2][threadIdx.x] + bred[3][threadIdx.x]);
   if (wv == 0 && colok) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -801,7 +882,7 @@ inline int grid_for(long n, int cap) {
   return (int)(b < 1 ? 1 : b);
 }
 
-template <int W, int TR, int TC, int BN, int WP, int WC>
+template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3, int ABL = 0>
 void launch_conv(ConvB16Params p, hipStream_t s) {
   constexpr int BM = TR > 0 ? TR * TC : TC;
   if (TR > 0) p.ntp = ((p.rows + TR - 1) / TR) * (W / TC);
@@ -810,7 +891,7 @@ void launch_conv(ConvB16Params p, hipStream_t s) {
   long blocks;
   if (p.nct <= 8 && (8 % p.nct) == 0) { const int g = 8 / p.nct; blocks = ((p.ntp + g - 1) / g) * 8; }
   else blocks = ((p.ntp + 7) / 8) * 8 * p.nct;
-  conv_bf16_kernel<W, TR, TC, BN, WP, WC><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
+  conv_bf16_kernel<W, TR, TC, BN, WP, WC, D, ABL><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
 }
 
 // tile choice per map width and output-channel count:
@@ -820,16 +901,33 @@ void launch_conv(ConvB16Params p, hipStream_t s) {
 //                  (K is only 576 deep there) hides behind the other's main loop
 //   14 x 14 maps : 57 pixel tiles only - 128-channel tiles (4 x 57 = 228 workgroups) fill the 256 CUs, 256-channel
 //                  tiles (114) would leave half of them idle
-template <int W, int TR, int TC>
+// UMPR_B16_CFG (A/B runs): tile for the layers with >= 256 output channels.  0: 256 px x 256 ch, 8 waves (one workgroup
+// per CU); 1: 256 x 128, 4 waves of 128 x 64 (80 KB of LDS: two workgroups per CU, their barriers interleave);
+// 2: 512 x 128, 8 waves of 128 x 64
+const int g_b16_cfg = [] { const char* v = getenv("UMPR_B16_CFG"); return v ? atoi(v) : 0; }();
+
+int conv_bn_for(int M, int W) {
+  if (M % 256 == 0 && W != 14 && g_b16_cfg == 0) return 256;
+  return M % 128 == 0 ? 128 : 64;
+}
+
+template <int W, int TR, int TC, int TR2, int TC2>
 int dispatch_conv_w(const ConvB16Params& p, hipStream_t s) {
-  if (p.M % 256 == 0 && W != 14) launch_conv<W, TR, TC, 256, 2, 4>(p, s);
-  else if (p.M % 128 == 0) launch_conv<W, TR, TC, 128, 4, 2>(p, s);
+  const int BN = conv_bn_for(p.M, W);
+  static const int deep = [] { const char* v = getenv("UMPR_B16_D"); return v ? atoi(v) : 3; }();
+  static const int abl = [] { const char* v = getenv("UMPR_B16_ABL"); return v ? atoi(v) : 0; }();
+  if (BN == 256 && W == 28 && abl == 1) launch_conv<W, TR, TC, 256, 2, 4, 3, 1>(p, s);
+  else if (BN == 256 && W == 28 && abl == 2) launch_conv<W, TR, TC, 256, 2, 4, 3, 2>(p, s);
+  else if (BN == 256 && W == 28 && abl == 3) launch_conv<W, TR, TC, 256, 2, 4, 3, 3>(p, s);
+  else if (BN == 256 && deep == 5) launch_conv<W, TR, TC, 256, 2, 4, 5>(p, s);
+  else if (BN == 256) launch_conv<W, TR, TC, 256, 2, 4>(p, s);
+  else if (BN == 128 && p.M % 256 == 0 && W != 14 && g_b16_cfg == 1) launch_conv<W, TR, TC, 128, 2, 2>(p, s);
+  else if (BN == 128 && p.M % 256 == 0 && W != 14 && g_b16_cfg == 2) launch_conv<W, TR2, TC2, 128, 4, 2>(p, s);
+  else if (BN == 128) launch_conv<W, TR, TC, 128, 4, 2>(p, s);
   else if (p.M % 64 == 0) launch_conv<W, TR, TC, 64, 4, 1>(p, s);
   else return -1;
   return 0;
 }
-
-int conv_bn_for(int M, int W) { return (M % 256 == 0 && W != 14) ? 256 : (M % 128 == 0 ? 128 : 64); }
 
 constexpr int kWgradB16Wgs = 256;   // workgroups per launch the split-K factor aims at: one per CU (LDS admits one)
 
@@ -868,7 +966,8 @@ size_t umpr_conv_bf16_pack_bytes(int Cin, int Cout) { return (size_t)Cin * Cout 
 // conv^T(x[C = Cout]) * [mask > 0].  x, y, mask: pointers to the START of plane 0 (incl. the lead guard) of CB8-PF
 // tensors of geometry g.  wpack: scratch of umpr_conv_bf16_pack_bytes.  The output's guards are zeroed here.
 int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const float* bias, const void* mask, void* y,
-                       const UmprPF& g, int Cin, int Cout, int relu, void* wpack, size_t wpack_bytes, hipStream_t s) {
+                       const UmprPF& g, int Cin, int Cout, int relu, void* wpack, size_t wpack_bytes, hipStream_t s,
+                       bool zero_guards) {
   const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
   UMPR_REQUIRE(C % 32 == 0 && M % 64 == 0, "conv_bf16: channels (%d -> %d) must be multiples of 32 / 64", C, M);
   UMPR_REQUIRE(g.H == g.W && (g.W == 224 || g.W == 112 || g.W == 56 || g.W == 28 || g.W == 14),
@@ -879,8 +978,10 @@ int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const floa
   pack_weights_bf16_kernel<<<grid_for((long)M * C * 9, 2048), 256, 0, s>>>(w, wp, M, C, Cin, BN, transposed);
   UMPR_LAUNCH_CHECK("pack_weights_bf16");
   bf16_t* y0 = static_cast<bf16_t*>(y);
-  zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), M / 8), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);
-  UMPR_LAUNCH_CHECK("zero_guards");
+  if (zero_guards) {
+    zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), M / 8), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);
+    UMPR_LAUNCH_CHECK("zero_guards");
+  }
   ConvB16Params p;
   p.x = static_cast<const bf16_t*>(x) + g.lead * 8; p.xps = g.ps;
   p.wp = wp; p.bias = bias;
@@ -890,11 +991,11 @@ int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const floa
   UmprProfScope prof(transposed ? UMPR_K_B16_DGRAD : UMPR_K_B16_FWD, 2.0 * (double)g.ptot * M * C * 9, s);
   int rc;
   switch (g.W) {
-    case 224: rc = dispatch_conv_w<224, 8, 32>(p, s); break;
-    case 112: rc = dispatch_conv_w<112, 16, 16>(p, s); break;
-    case 56: rc = dispatch_conv_w<56, 0, 256>(p, s); break;
-    case 28: rc = dispatch_conv_w<28, 0, 256>(p, s); break;
-    default: rc = dispatch_conv_w<14, 0, 256>(p, s); break;
+    case 224: rc = dispatch_conv_w<224, 8, 32, 16, 32>(p, s); break;
+    case 112: rc = dispatch_conv_w<112, 16, 16, 32, 16>(p, s); break;
+    case 56: rc = dispatch_conv_w<56, 0, 256, 0, 512>(p, s); break;
+    case 28: rc = dispatch_conv_w<28, 0, 256, 0, 512>(p, s); break;
+    default: rc = dispatch_conv_w<14, 0, 256, 0, 512>(p, s); break;
   }
   UMPR_REQUIRE(rc == 0, "conv_bf16: unsupported channel count %d", M);
   UMPR_LAUNCH_CHECK("conv_bf16");
@@ -918,6 +1019,7 @@ int umpr_wgrad_bf16_run(const void* dy, const void* x, float* dw, float* db, con
   p.x = static_cast<const bf16_t*>(x) + g.lead * 8; p.xps = g.ps;
   p.slab = ws; p.Cin = Cin; p.Cout = Cout;
   const WgradPlan q = wgrad_plan(g, Cin, Cout);
+  p.bslab = db ? ws + (size_t)q.splits * 9 * Cout * Cin : nullptr;
   {
     UmprProfScope prof(UMPR_K_B16_WGRAD, 2.0 * (double)g.ptot * Cout * Cin * 9, s);
     if (q.big) {
@@ -939,14 +1041,11 @@ int umpr_wgrad_bf16_run(const void* dy, const void* x, float* dw, float* db, con
     }
   }
   UMPR_LAUNCH_CHECK("wgrad_bf16");
-  const int splits = q.splits;
-  float* bslab = nullptr;
-  if (db) {
-    bslab = ws + (size_t)splits * 9 * Cout * Cin;
-    bias_grad_bf16_kernel<<<dim3(Cout / 8, splits), 256, 0, s>>>(p.dy, g.ps, g.ptot, Cout, splits, bslab);
-    UMPR_LAUNCH_CHECK("bias_grad_bf16");
-  }
-  return umpr_wgrad_reduce(ws, bslab, splits, Cout, Cin, dw, db, accumulate, s);
+  const long per = (long)9 * Cout * Cin;
+  wgrad_reduce_linear_kernel<<<grid_for(per / 4 + Cout, 2048), 256, 0, s>>>(ws, db ? p.bslab : nullptr, q.splits, per, Cout,
+                                                                            dw, db, accumulate);
+  UMPR_LAUNCH_CHECK("wgrad_reduce_linear");
+  return 0;
 }
 
 int umpr_nchw_to_cb8(const float* x, void* y, const UmprPF& g, int C, hipStream_t s) {
@@ -966,9 +1065,10 @@ int umpr_cb8_to_nchw(const void* x, float* y, const UmprPF& g, int C, hipStream_
   return 0;
 }
 
-int umpr_maxpool2_bf16_fwd_run(const void* x, void* y, const UmprPF& gi, const UmprPF& go, int C, hipStream_t s) {
+int umpr_maxpool2_bf16_fwd_run(const void* x, void* y, const UmprPF& gi, const UmprPF& go, int C, hipStream_t s,
+                               bool zero_guards) {
   bf16_t* y0 = static_cast<bf16_t*>(y);
-  zero_guards_kernel<<<dim3(grid_for(go.ps - go.ptot, 64), C / 8), 256, 0, s>>>(y0, go.ps, go.lead, go.ptot);
+  if (zero_guards) zero_guards_kernel<<<dim3(grid_for(go.ps - go.ptot, 64), C / 8), 256, 0, s>>>(y0, go.ps, go.lead, go.ptot);
   maxpool2_bf16_fwd_kernel<<<dim3(grid_for(go.ptot, 4096), C / 8), 256, 0, s>>>(
       static_cast<const bf16_t*>(x) + gi.lead * 8, gi.ps, y0 + go.lead * 8, go.ps, gi.H, gi.W, go.ptot);
   UMPR_LAUNCH_CHECK("maxpool2_bf16_fwd");
@@ -987,10 +1087,11 @@ int umpr_maxpool2_bf16_bwd_run(const void* x, const void* gy, void* gx, const Um
 }
 
 // first VGG layer in the bf16 path: fp32 images [N][3][H][W] -> bf16 CB8-PF [64 channels], ReLU fused
-int umpr_conv1_bf16_fwd(const float* x, const float* w, const float* bias, void* y, const UmprPF& g, hipStream_t s) {
+int umpr_conv1_bf16_fwd(const float* x, const float* w, const float* bias, void* y, const UmprPF& g, hipStream_t s,
+                        bool zero_guards) {
   UMPR_REQUIRE(g.W % 32 == 0, "conv1_bf16: width %d is not a multiple of 32", g.W);
   bf16_t* y0 = static_cast<bf16_t*>(y);
-  zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), 8), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);
+  if (zero_guards) zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), 8), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);
   pf_zero_pads_kernel<<<dim3((unsigned)(g.rows < 4096 ? g.rows : 4096), 8), 64, 0, s>>>(y0 + g.lead * 8, g.ps, g.H, g.W, g.rows);
   Conv1B16Params p{x, w, bias, y0 + g.lead * 8, g.ps, g.N, g.H, g.W};
   UmprProfScope prof(UMPR_K_B16_FWD, 2.0 * (double)g.N * g.H * g.W * 64 * 27, s);
@@ -1007,17 +1108,26 @@ int umpr_conv1_bf16_wgrad(const void* dy, const float* x, float* dw, float* db, 
                           float* ws, size_t ws_bytes, hipStream_t s) {
   UMPR_REQUIRE(g.W % 16 == 0 && ws_bytes >= umpr_conv1_bf16_wgrad_ws_bytes(), "conv1_bf16_wgrad: bad width / workspace");
   const bf16_t* d0 = static_cast<const bf16_t*>(dy) + g.lead * 8;
-  Wgrad1B16Params p{d0, g.ps, x, ws, g.N, g.H, g.W};
+  float* bslab = db ? ws + (size_t)kWgrad1Splits * 9 * 64 * 3 : nullptr;
+  Wgrad1B16Params p{d0, g.ps, x, ws, bslab, g.N, g.H, g.W};
   {
     UmprProfScope prof(UMPR_K_B16_WGRAD, 2.0 * (double)g.N * g.H * g.W * 64 * 27, s);
     conv1_bf16_wgrad_kernel<<<kWgrad1Splits, 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("conv1_bf16_wgrad");
-  float* bslab = nullptr;
-  if (db) {
-    bslab = ws + (size_t)kWgrad1Splits * 9 * 64 * 3;
-    bias_grad_bf16_kernel<<<dim3(8, kWgrad1Splits), 256, 0, s>>>(d0, g.ps, g.ptot, 64, kWgrad1Splits, bslab);
-    UMPR_LAUNCH_CHECK("bias_grad_bf16");
-  }
   return umpr_wgrad_reduce(ws, bslab, kWgrad1Splits, 64, 3, dw, db, accumulate, s);
+}
+
+// guards of up to 20 CB8-PF tensors (start-of-plane pointers) in one launch
+int umpr_pf_zero_guards_multi(void* const* bases, const UmprPF* geos, const int* channels, int n, hipStream_t s) {
+  UMPR_REQUIRE(n >= 1 && n <= 20, "zero_guards_multi: %d tensors", n);
+  GuardSet gs;
+  gs.n = n;
+  for (int i = 0; i < n; ++i) {
+    gs.base[i] = static_cast<bf16_t*>(bases[i]); gs.ps[i] = geos[i].ps; gs.lead[i] = geos[i].lead; gs.ptot[i] = geos[i].ptot;
+    gs.planes[i] = (channels[i] + 7) / 8;
+  }
+  zero_guards_multi_kernel<<<dim3(64, n), 256, 0, s>>>(gs);
+  UMPR_LAUNCH_CHECK("zero_guards_multi");
+  return 0;
 }

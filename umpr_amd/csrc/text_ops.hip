@@ -628,6 +628,15 @@ inline int nblocks(long n, int cap = 4096) {
 }  // namespace
 
 // ---- internal host wrappers --------------------------------------------------------------------------------
+__global__ void copy_or_add_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, int accumulate) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+int umpr_copy_or_add(const float* src, float* dst, long n, int accumulate, hipStream_t s) {
+  copy_or_add_kernel<<<nblocks(n), 256, 0, s>>>(src, dst, n, accumulate);
+  UMPR_LAUNCH_CHECK("copy_or_add");
+  return 0;
+}
 int umpr_fill(float* p, long n, float v, hipStream_t s) {
   fill_kernel<<<nblocks(n), 256, 0, s>>>(p, n, v);
   UMPR_LAUNCH_CHECK("fill");

@@ -19,6 +19,7 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream);
 
 // small shared launch helpers (util.hip)
 int umpr_fill(float* p, long n, float v, hipStream_t s);
+int umpr_copy_or_add(const float* src, float* dst, long n, int accumulate, hipStream_t s);   // dst (+)= src
 
 // visual head + fusion + losses (text_ops.hip)
 struct UmprHead {
@@ -78,17 +79,21 @@ UmprPF umpr_pf(int N, int H, int W);
 size_t umpr_pf_bytes(const UmprPF& g, int C);
 size_t umpr_conv_bf16_pack_bytes(int Cin, int Cout);
 int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const float* bias, const void* mask, void* y,
-                       const UmprPF& g, int Cin, int Cout, int relu, void* wpack, size_t wpack_bytes, hipStream_t s);
+                       const UmprPF& g, int Cin, int Cout, int relu, void* wpack, size_t wpack_bytes, hipStream_t s,
+                       bool zero_guards = true);
+int umpr_pf_zero_guards_multi(void* const* bases, const UmprPF* geos, const int* channels, int n, hipStream_t s);
 size_t umpr_wgrad_bf16_ws_bytes(const UmprPF& g, int Cin, int Cout);
 int umpr_wgrad_bf16_run(const void* dy, const void* x, float* dw, float* db, const UmprPF& g, int Cin, int Cout,
                         int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
-int umpr_conv1_bf16_fwd(const float* x, const float* w, const float* bias, void* y, const UmprPF& g, hipStream_t s);
+int umpr_conv1_bf16_fwd(const float* x, const float* w, const float* bias, void* y, const UmprPF& g, hipStream_t s,
+                        bool zero_guards = true);
 size_t umpr_conv1_bf16_wgrad_ws_bytes();
 int umpr_conv1_bf16_wgrad(const void* dy, const float* x, float* dw, float* db, const UmprPF& g, int accumulate, float* ws,
                           size_t ws_bytes, hipStream_t s);
 int umpr_nchw_to_cb8(const float* x, void* y, const UmprPF& g, int C, hipStream_t s);
 int umpr_cb8_to_nchw(const void* x, float* y, const UmprPF& g, int C, hipStream_t s);
-int umpr_maxpool2_bf16_fwd_run(const void* x, void* y, const UmprPF& gi, const UmprPF& go, int C, hipStream_t s);
+int umpr_maxpool2_bf16_fwd_run(const void* x, void* y, const UmprPF& gi, const UmprPF& go, int C, hipStream_t s,
+                               bool zero_guards = true);
 int umpr_maxpool2_bf16_bwd_run(const void* x, const void* gy, void* gx, const UmprPF& gi, const UmprPF& go, int C,
                                hipStream_t s);
 

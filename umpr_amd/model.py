@@ -607,7 +607,7 @@ class UMPR(nn.Module):
     def _side_stream(device):
         st = _SIDE_STREAMS.get(device)
         if st is None:
-            st = _SIDE_STREAMS[device] = torch.cuda.Stream(device)
+            st = _SIDE_STREAMS[device] = torch.cuda.Stream(device, priority=int(os.environ.get("UMPR_TEXT_PRIO", "-1")))
         return st
 
     def _review(self, user_reviews, item_reviews, lu, ou, li, oi, emb):
