@@ -18,7 +18,8 @@ from torch import nn
 
 from ._lib import Workspace, lib, stream_ptr
 
-TEXT_STREAM = os.environ.get("UMPR_TEXT_STREAM", "1") != "0"   # text path on a side stream beside the VGG stack
+TEXT_STREAM = os.environ.get("UMPR_TEXT_STREAM", "1") != "0"   # text path on side streams beside the VGG stack
+TEXT_STREAMS = int(os.environ.get("UMPR_TEXT_STREAMS", "1"))    # 2: ReviewNet and ControlNet on streams of their own - measured SLOWER (14.9 vs 12.0 ms): with the wgrad and optimiser streams that makes five, more than the hardware queues ROCm maps streams onto, and two of them serialise
 _SIDE_STREAMS = {}
 H = 64          # config.gru_size the kernels are built for
 D = 2 * H
@@ -604,10 +605,12 @@ class UMPR(nn.Module):
         return both[0], both[1]
 
     @staticmethod
-    def _side_stream(device):
-        st = _SIDE_STREAMS.get(device)
+    def _side_stream(device, which=0):
+        """High-priority side streams of the text path: its many small latency-bound kernels should not queue behind the
+        big convolution grids.  Stream 0 carries the ReviewNet, stream 1 the ControlNet (independent until the head)."""
+        st = _SIDE_STREAMS.get((device, which))
         if st is None:
-            st = _SIDE_STREAMS[device] = torch.cuda.Stream(device, priority=int(os.environ.get("UMPR_TEXT_PRIO", "-1")))
+            st = _SIDE_STREAMS[(device, which)] = torch.cuda.Stream(device, priority=int(os.environ.get("UMPR_TEXT_PRIO", "-1")))
         return st
 
     def _review(self, user_reviews, item_reviews, lu, ou, li, oi, emb):
@@ -654,22 +657,26 @@ class UMPR(nn.Module):
         # The text path (many small, latency-bound kernels: GRUs, co-attention, heads) runs on a side stream beside the
         # VGG stack (MFMA-bound) and joins it at the head; autograd replays the same split in backward.
         main = torch.cuda.current_stream(device)
-        side = self._side_stream(device) if TEXT_STREAM else None
-        if side is not None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+        sides = [self._side_stream(device, 0), self._side_stream(device, 1 if TEXT_STREAMS >= 2 else 0)] if TEXT_STREAM else None
+        if sides is not None:
+            for st in set(sides):
+                st.wait_stream(main)
+            with torch.cuda.stream(sides[0]):
                 rr = self._review(user_reviews, item_reviews, lu, ou, li, oi, emb)
+            with torch.cuda.stream(sides[1]):
                 cu, ci, pp, pn = self._control(user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui, emb)
             for t in (user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui):
-                t.record_stream(side)
+                for st in set(sides):
+                    t.record_stream(st)
         else:
             rr = self._review(user_reviews, item_reviews, lu, ou, li, oi, emb)
             cu, ci, pp, pn = self._control(user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui, emb)
         vn = self.visual_net
         V, Pc = photos.shape[1], photos.shape[2]
         vgg = vn.vgg16[0](photos.reshape(B * V * Pc, *photos.shape[3:]).float())
-        if side is not None:
-            main.wait_stream(side)
+        if sides is not None:
+            for st in set(sides):
+                main.wait_stream(st)
             for t in (rr, cu, ci, pp, pn):
                 t.record_stream(main)
         pred, loss, terms = _Head.apply(rr, cu, ci, pp, pn, vgg, vn.pos_v_emb, vn.neg_v_emb, vn.linear.weight,
