@@ -191,7 +191,7 @@ def test_embed_gru(L, dev, N, Lmax, E, seed):
     lens, order = UMPR._host_perm(lengths, dev)
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
     w = [P["g." + n + s].detach().to(dev).requires_grad_(True) for s in ("", "_reverse") for n in names]
-    out = _EmbedGru.apply(ids.to(dev), lens, order, emb.to(dev), *w)
+    out = _EmbedGru.apply(ids.to(dev), lens, order, emb.to(dev), 0, *w)
     check(f"gru fwd N{N} L{Lmax} E{E}", out, out_ref, atol=2e-5)
     out.backward(gout.to(dev))
     for t, (s, n) in zip(w, [(s, n) for s in ("", "_reverse") for n in names]):
@@ -627,7 +627,7 @@ def test_full_size_properties(L, dev):
     lens, order = UMPR._host_perm(lengths, dev)
     ident = torch.arange(N, dtype=torch.int32, device=dev)
     with torch.no_grad():
-        out_sorted = _EmbedGru.apply(ids.to(dev), lens, order, emb, *w)      # tiles grouped by length, permuted rows
+        out_sorted = _EmbedGru.apply(ids.to(dev), lens, order, emb, 0, *w)      # tiles grouped by length, permuted rows
     out_ident = torch.empty(N, Lm, 128, device=dev)
     wsb = L.size("umpr_embed_gru_bidir_ws_bytes", N, Lm, E)
     ws = torch.empty(wsb // 4 + 64, device=dev)

@@ -28,6 +28,18 @@ if qk:
     print(f"per-{qk} busy time in the second half of the trace ({(t1 - half)/1e6:.2f} ms):")
     for k, v in sorted(per.items(), key=lambda kv: -kv[1][0]):
         print(f"  {qk} {k}: busy {v[0]/1e6:7.2f} ms in {v[1]:5d} dispatches, span {(v[3]-v[2])/1e6:7.2f} ms")
+    # top kernels of the second-busiest queue (the text stream in the full model)
+    order = sorted(per.items(), key=lambda kv: -kv[1][0])
+    if len(order) > 1:
+        q2 = order[1][0]
+        agg = collections.defaultdict(lambda: [0, 0])
+        for r in rows:
+            if r[qk] == q2 and int(r['Start_Timestamp']) >= half:
+                k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:70]
+                agg[k][0] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); agg[k][1] += 1
+        print(f"top kernels on {qk} {q2} (per step = /4):")
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]:
+            print(f"   {k:70s} n={v[1]:4d} avg_us={v[0]/v[1]/1e3:8.1f} per_step_ms={v[0]/4e6:6.3f}")
     # idle gaps > 40 us on the busiest queue inside the last step of the trace (between which kernels does it wait?)
     mainq = max(per.items(), key=lambda kv: kv[1][0])[0]
     mq = sorted((r for r in rows if r[qk] == mainq), key=lambda r: int(r['Start_Timestamp']))

@@ -66,10 +66,12 @@ def _grad_returns(params, dst, direct):
 
 # --------------------------------------------------------------------------------------------- K1-K3
 class _EmbedGru(torch.autograd.Function):
-    """nn.Embedding + ImprovedRnn(nn.GRU bidirectional) (src/model.py:262-264, 12-21)."""
+    """nn.Embedding + ImprovedRnn(nn.GRU bidirectional) (src/model.py:262-264, 12-21).  ``split`` > 0: the batch is two
+    review tensors of ``split`` sequences each run in one launch (UMPR._pair); their outputs come back as two tensors
+    (views of one buffer) and their gradients are joined by one concatenation instead of autograd's slice bookkeeping."""
 
     @staticmethod
-    def forward(ctx, ids, lengths, order, emb, *w):
+    def forward(ctx, ids, lengths, order, emb, split, *w):
         N, L = ids.shape
         E = emb.shape[1]
         need = any(ctx.needs_input_grad)
@@ -77,26 +79,38 @@ class _EmbedGru(torch.autograd.Function):
         saved = torch.empty(2, N, L, 4, H, device=ids.device, dtype=torch.float32) if need else None
         ws, wsb = _ws(lib().size("umpr_embed_gru_bidir_ws_bytes", N, L, E), ids.device)
         ctx.param_objs = w
+        ctx.split = int(split)
         w = [_c(x) for x in w]
         lib().call("umpr_embed_gru_bidir_fwd", ids, emb, E, *w, lengths, order, order, N, L, out, saved, ws, wsb,
                    stream_ptr())
         if need:
-            ctx.save_for_backward(ids, lengths, order, emb, w[1], w[5], out, saved)
+            ctx.save_for_backward(ids, lengths, order, emb, w[1], w[5], saved)
+            ctx.out = out        # the kernel's own output buffer (with split, the returned tensors are views of it)
+        if split:
+            return out[:split], out[split:]
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        ids, lengths, order, emb, whh_f, whh_r, out, saved = ctx.saved_tensors
+    def backward(ctx, *douts):
+        ids, lengths, order, emb, whh_f, whh_r, saved = ctx.saved_tensors
+        out = ctx.out
         N, L = ids.shape
         E = emb.shape[1]
         dev = ids.device
+        if ctx.split:
+            parts = [d if d is not None else torch.zeros(n, L, D, device=dev)
+                     for d, n in zip(douts, (ctx.split, N - ctx.split))]
+            dout = torch.cat(parts)
+        else:
+            dout = _c(douts[0])
         # the reference shares one GRU between the user and item reviews (and one between the three C-Net calls): the first
         # backward of a step overwrites the gradient slices of the optimiser's arena, the later ones add in place
         g, direct, acc = _grad_targets(ctx.param_objs, can_accumulate=True)
         ws, wsb = _ws(lib().size("umpr_embed_gru_bidir_ws_bytes", N, L, E), dev)
-        lib().call("umpr_embed_gru_bidir_bwd_acc", ids, emb, E, whh_f, whh_r, lengths, order, order, N, L, _c(dout), out,
+        lib().call("umpr_embed_gru_bidir_bwd_acc", ids, emb, E, whh_f, whh_r, lengths, order, order, N, L, dout, out,
                    saved, *g, int(acc), ws, wsb, stream_ptr())
-        return (None, None, None, None, *_grad_returns(ctx.param_objs, g, direct))
+        ctx.out = None
+        return (None, None, None, None, None, *_grad_returns(ctx.param_objs, g, direct))
 
 
 # --------------------------------------------------------------------------------------------- K4-K7
@@ -439,9 +453,9 @@ class ImprovedRnn(nn.Module):
         return (m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0, m.weight_ih_l0_reverse,
                 m.weight_hh_l0_reverse, m.bias_ih_l0_reverse, m.bias_hh_l0_reverse)
 
-    def forward(self, ids, lengths_dev, order_dev, emb):
-        """ids [N,L] int64 on device; lengths/order int32 on device -> [N, L, 128]."""
-        return _EmbedGru.apply(ids, lengths_dev, order_dev, emb, *self.weights())
+    def forward(self, ids, lengths_dev, order_dev, emb, split=0):
+        """ids [N,L] int64 on device; lengths/order int32 on device -> [N, L, 128] (two tensors when split > 0)."""
+        return _EmbedGru.apply(ids, lengths_dev, order_dev, emb, split, *self.weights())
 
 
 class RNet(nn.Module):
@@ -613,21 +627,35 @@ class UMPR(nn.Module):
             st = _SIDE_STREAMS[(device, which)] = torch.cuda.Stream(device, priority=int(os.environ.get("UMPR_TEXT_PRIO", "-1")))
         return st
 
-    def _review(self, user_reviews, item_reviews, lu, ou, li, oi, emb):
+    @staticmethod
+    def _pair(user_reviews, item_reviews, lu, ou, li, oi):
+        """User and item reviews as ONE batch of 2N sequences for the GRUs they share (src/model.py:45-46 and :183-184 call
+        the same module on both): the recurrent kernels are bound by the latency of their <= 20 dependent time steps, not by
+        work, so one launch over 2N sequences costs what a launch over N does, and the input-projection GEMM doubles its M.
+        Each half keeps its own permutation (the reference's double un-sort is per call): item rows and their destination
+        rows are offset by N."""
         B, S, L = user_reviews.shape
+        N = B * S
+        ids = torch.cat([user_reviews.view(N, L), item_reviews.view(N, L)])
+        return ids, torch.cat([lu, li]), torch.cat([ou, oi + N]), N
+
+    def _review(self, pair, S, L, emb):
+        ids, lens, order, N = pair
+        B = N // S
         rn = self.review_net
-        gru_u = rn.r_net.gru(user_reviews.view(B * S, L), lu, ou, emb).view(B, S * L, D)
-        gru_i = rn.r_net.gru(item_reviews.view(B * S, L), li, oi, emb).view(B, S * L, D)
+        g_u, g_i = rn.r_net.gru(ids, lens, order, emb, split=N)
+        gru_u, gru_i = g_u.view(B, S * L, D), g_i.view(B, S * L, D)
         return _ReviewHead.apply(gru_u, gru_i, S, L, rn.r_net.M, rn.s_net_u.Ms, rn.s_net_u.Ws, rn.s_net_i.Ms,
                                  rn.s_net_i.Ws, rn.linear_u.weight, rn.linear_i.weight, self.compute_dtype == "bf16")
 
-    def _control(self, user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui, emb):
-        B, S, L = user_reviews.shape
+    def _control(self, pair, S, L, ui_reviews, lui, oui, emb):
+        ids, lens, order, N = pair
+        B = N // S
         _, S_ui, L_ui = ui_reviews.shape
         cn = self.control_net
         c_ui = cn.c_net.gru(ui_reviews.view(B * S_ui, L_ui), lui, oui, emb).view(B, S_ui * L_ui, D)
-        c_u = cn.c_net.gru(user_reviews.view(B * S, L), lu, ou, emb).view(B, S * L, D)
-        c_i = cn.c_net.gru(item_reviews.view(B * S, L), li, oi, emb).view(B, S * L, D)
+        g_u, g_i = cn.c_net.gru(ids, lens, order, emb, split=N)
+        c_u, c_i = g_u.view(B, S * L, D), g_i.view(B, S * L, D)
         return _Control.apply(c_ui, c_u, c_i, (B, S_ui, L_ui, S, L), cn.c_net.threshold, cn.c_net.cnn[0].weight,
                               cn.c_net.cnn[0].bias, cn.c_net.linear[0].weight, cn.c_net.linear[0].bias, cn.s_net.Ms,
                               cn.s_net.Ws, cn.ss_net.linear[0].weight, cn.ss_net.linear[0].bias)
@@ -648,7 +676,7 @@ class UMPR(nn.Module):
         li, oi = self._host_perm(i_lengths, device)
         fus = self.linear_fusion[0]
         if self.review_net_only:
-            rr = self._review(user_reviews, item_reviews, lu, ou, li, oi, emb)
+            rr = self._review(self._pair(user_reviews, item_reviews, lu, ou, li, oi), S, L, emb)
             pred, loss, terms = _Head.apply(rr, None, None, None, None, None, None, None, None, None, fus.weight,
                                             fus.bias, labels, 0.0, 0, 0)
             self.last_loss_terms = terms
@@ -662,15 +690,19 @@ class UMPR(nn.Module):
             for st in set(sides):
                 st.wait_stream(main)
             with torch.cuda.stream(sides[0]):
-                rr = self._review(user_reviews, item_reviews, lu, ou, li, oi, emb)
+                pair = self._pair(user_reviews, item_reviews, lu, ou, li, oi)
+                rr = self._review(pair, S, L, emb)
+            if sides[1] is not sides[0]:
+                sides[1].wait_stream(sides[0])
             with torch.cuda.stream(sides[1]):
-                cu, ci, pp, pn = self._control(user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui, emb)
+                cu, ci, pp, pn = self._control(pair, S, L, ui_reviews, lui, oui, emb)
             for t in (user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui):
                 for st in set(sides):
                     t.record_stream(st)
         else:
-            rr = self._review(user_reviews, item_reviews, lu, ou, li, oi, emb)
-            cu, ci, pp, pn = self._control(user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui, emb)
+            pair = self._pair(user_reviews, item_reviews, lu, ou, li, oi)
+            rr = self._review(pair, S, L, emb)
+            cu, ci, pp, pn = self._control(pair, S, L, ui_reviews, lui, oui, emb)
         vn = self.visual_net
         V, Pc = photos.shape[1], photos.shape[2]
         vgg = vn.vgg16[0](photos.reshape(B * V * Pc, *photos.shape[3:]).float())
