@@ -10,7 +10,7 @@ python3 - /tmp/pb_$tag/p_kernel_trace.csv <<'PY'
 import csv, sys, collections
 # longest individual dispatches of the generic kernels (which GEMM / reduce calls carry the time)
 rows = list(csv.DictReader(open(sys.argv[1])))
-sel = [r for r in rows if any(k in r['Kernel_Name'] for k in ('gemm_f32', 'splitk_reduce', 'colsum', 'wgrad_reduce'))]
+sel = [r for r in rows if any(k in r['Kernel_Name'] for k in ('gemm_f32', 'splitk_reduce', 'colsum', 'wgrad_reduce', 'fc_'))]
 sel.sort(key=lambda r: int(r['End_Timestamp']) - int(r['Start_Timestamp']), reverse=True)
 # per-queue (stream) busy time: which stream is the critical path
 hdr = rows[0].keys()

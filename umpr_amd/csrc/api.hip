@@ -388,6 +388,7 @@ int umpr_vgg16_features_fwd(const float* images, const float* const* params, int
 }
 
 namespace {
+const bool g_fc_small = [] { const char* v = getenv("UMPR_FC_SMALL"); return !(v && v[0] == '0'); }();
 // classifier activations: pool5 input [n][25088], ReLU outputs of fc1 / fc2 and their dropout outputs ([n][4096] each)
 struct ClsActs { const float* pool5; float* fc[2]; float* drop[2]; };
 
@@ -396,13 +397,21 @@ int classifier_fwd_impl(const float* const* params, int n, int train, int use_ma
   // AdaptiveAvgPool2d(7) is the identity on the 7x7 map a 224x224 image produces
   const float* x = A.pool5;
   for (int j = 0; j < 3; ++j) {
-    UmprGemm g;
-    g.A = x; g.lda = kFc[j][0]; g.B = params[26 + 2 * j]; g.ldb = kFc[j][0]; g.transB = true;
-    g.C = j < 2 ? A.fc[j] : out; g.ldc = kFc[j][1]; g.M = n; g.N = kFc[j][1]; g.K = kFc[j][0];
-    g.bias = params[27 + 2 * j]; g.bias_mode = 1; g.act = j < 2 ? UMPR_ACT_RELU : UMPR_ACT_NONE;
-    g.split_k = 0; g.ws = ws; g.ws_bytes = ws_bytes;
-    if (int rc = umpr_gemm(g, s)) return rc;
-    x = g.C;
+    float* y = j < 2 ? A.fc[j] : out;
+    const int act = j < 2 ? UMPR_ACT_RELU : UMPR_ACT_NONE;
+    if (g_fc_small && umpr_fc_small_ok(n, kFc[j][1], kFc[j][0])) {
+      // batch-sized M: register-streaming kernels (fc_small.hip) instead of the LDS-tiled GEMM
+      if (int rc = umpr_fc_small_fwd(x, params[26 + 2 * j], params[27 + 2 * j], y, n, kFc[j][1], kFc[j][0], act, ws,
+                                     ws_bytes, s)) return rc;
+    } else {
+      UmprGemm g;
+      g.A = x; g.lda = kFc[j][0]; g.B = params[26 + 2 * j]; g.ldb = kFc[j][0]; g.transB = true;
+      g.C = y; g.ldc = kFc[j][1]; g.M = n; g.N = kFc[j][1]; g.K = kFc[j][0];
+      g.bias = params[27 + 2 * j]; g.bias_mode = 1; g.act = act;
+      g.split_k = 0; g.ws = ws; g.ws_bytes = ws_bytes;
+      if (int rc = umpr_gemm(g, s)) return rc;
+    }
+    x = y;
     if (j < 2 && (train || use_masks)) {
       float* y = A.drop[j];
       if (int rc = umpr_dropout_fwd_impl(x, y, masks + (size_t)j * n * 4096, (long)n * 4096, 0.5f,
@@ -471,16 +480,26 @@ int classifier_bwd_impl(const float* const* params, int n, int train, const ClsA
                                          (long)n * 4096, 0.5f, s)) return rc;
       g = cur; float* t = cur; cur = oth; oth = t;
     }
-    UmprGemm w;  // dW[fout][fin] = g^T xin
-    w.A = g; w.lda = fout; w.transA = true; w.B = xin; w.ldb = fin; w.C = grads[26 + 2 * j]; w.ldc = fin;
-    w.M = fout; w.N = fin; w.K = n;
-    if (int rc = umpr_gemm(w, s)) return rc;
+    const bool small = g_fc_small && umpr_fc_small_ok(n, fout, fin);
+    if (small) {  // dW[fout][fin] = g^T xin
+      if (int rc = umpr_fc_small_dw(g, xin, grads[26 + 2 * j], n, fout, fin, s)) return rc;
+    } else {
+      UmprGemm w;
+      w.A = g; w.lda = fout; w.transA = true; w.B = xin; w.ldb = fin; w.C = grads[26 + 2 * j]; w.ldc = fin;
+      w.M = fout; w.N = fin; w.K = n;
+      if (int rc = umpr_gemm(w, s)) return rc;
+    }
     if (int rc = umpr_colsum_rows(g, n, fout, fout, grads[27 + 2 * j], 0, s)) return rc;
-    UmprGemm d;  // dx[n][fin] = g W
-    d.A = g; d.lda = fout; d.B = params[26 + 2 * j]; d.ldb = fin; d.C = j == 0 ? d_pool5 : cur; d.ldc = fin; d.M = n;
-    d.N = fin; d.K = fout; d.split_k = 0; d.ws = scratch; d.ws_bytes = slab_bytes;
-    if (int rc = umpr_gemm(d, s)) return rc;
-    g = d.C; float* t = cur; cur = oth; oth = t;
+    float* dxo = j == 0 ? d_pool5 : cur;
+    if (small) {  // dx[n][fin] = g W
+      if (int rc = umpr_fc_small_dx(g, params[26 + 2 * j], dxo, n, fout, fin, scratch, slab_bytes, s)) return rc;
+    } else {
+      UmprGemm d;
+      d.A = g; d.lda = fout; d.B = params[26 + 2 * j]; d.ldb = fin; d.C = dxo; d.ldc = fin; d.M = n;
+      d.N = fin; d.K = fout; d.split_k = 0; d.ws = scratch; d.ws_bytes = slab_bytes;
+      if (int rc = umpr_gemm(d, s)) return rc;
+    }
+    g = dxo; float* t = cur; cur = oth; oth = t;
   }
   return 0;
 }

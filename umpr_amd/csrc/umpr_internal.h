@@ -17,6 +17,15 @@ struct UmprGemm {
 };
 int umpr_gemm(const UmprGemm& g, hipStream_t stream);
 
+// fc_small.hip - batch-sized fully connected layers (register-streaming fp32 MFMA, no LDS)
+bool umpr_fc_small_ok(int M, int N, int K);
+size_t umpr_fc_small_ws_bytes(int M, int N, int K);
+int umpr_fc_small_fwd(const float* x, const float* W, const float* bias, float* out, int M, int N, int K, int act,
+                      float* ws, size_t ws_bytes, hipStream_t s);
+int umpr_fc_small_dx(const float* g, const float* W, float* dx, int M, int N, int K, float* ws, size_t ws_bytes,
+                     hipStream_t s);
+int umpr_fc_small_dw(const float* g, const float* x, float* dW, int M, int N, int K, hipStream_t s);
+
 // small shared launch helpers (util.hip)
 int umpr_fill(float* p, long n, float v, hipStream_t s);
 int umpr_copy_or_add(const float* src, float* dst, long n, int accumulate, hipStream_t s);   // dst (+)= src
