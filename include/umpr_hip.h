@@ -164,6 +164,14 @@ int umpr_vgg16_classifier_bwd(const float* const* params, int n_img, int train, 
 size_t umpr_vgg16_features_bwd_ws_bytes(int n_img);
 int umpr_vgg16_features_bwd(const float* images, const float* const* params, int n_img, const float* acts,
                             const float* d_pool5, float* const* grads, float* ws, size_t ws_bytes, void* stream);
+/* Data parallel: `cb(block, user)` is called on the calling thread each time umpr_vgg16_features_bwd /
+ * umpr_vgg16_bf16_features_bwd has ENQUEUED all kernels of one VGG block (4, 3, 2, 1, 0), i.e. as soon as that block's
+ * weight gradients are ordered on umpr_vgg16_wgrad_stream() (the library's side stream; NULL when weight gradients run on
+ * the caller's stream).  A host that owns flat gradient storage starts that block's all-reduce there, ordered behind that
+ * stream, while the blocks below are still being computed.  cb = NULL clears it. */
+typedef void (*umpr_block_callback)(int block, void* user);
+int umpr_vgg16_set_block_callback(umpr_block_callback cb, void* user);
+void* umpr_vgg16_wgrad_stream(void);
 /* per-layer entry points (also what the composite calls) */
 /* wpack / wt: scratch of umpr_conv3x3_pack_bytes(...) - packed weights, or on the 56/28/14 maps the Winograd
  * F(2x2,3x3) buffers (with a smaller scratch those layers fall back to the direct kernel) */

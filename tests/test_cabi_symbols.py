@@ -19,7 +19,7 @@ def parse_header():
         if args.strip() not in ("", "void"):
             for a in args.split(","):
                 a = a.strip()
-                if "*" in a:
+                if "*" in a or "umpr_block_callback" in a:      # pointers, incl. the function-pointer typedef
                     codes += "p"
                 elif "size_t" in a:
                     codes += "z"
@@ -35,7 +35,7 @@ def parse_header():
                     codes += "i"
                 else:
                     raise AssertionError(f"unparsed argument {a!r} of {name}")
-        rc = "s" if "char" in ret else ("z" if "size_t" in ret else "i")
+        rc = "s" if "char" in ret else ("z" if "size_t" in ret else ("p" if "void*" in ret.replace(" ", "") else "i"))
         protos[name] = (codes, rc)
     return protos
 

@@ -56,6 +56,7 @@ def main():
         model.eval()
         pred, loss = model(*mine)
         opt.zero_grad()
+        opt.arm_early(1.0 / mine.n_active)      # as train_step does: the classifier slice is updated behind its all-reduce
         loss.mean().backward()
         fired.append(red.fired)
         red.finish()

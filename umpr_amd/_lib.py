@@ -50,6 +50,8 @@ SIGNATURES = {
     "umpr_vgg16_fwd": ("ppiiiuppppzp", "i"),
     "umpr_vgg16_bwd": ("ppiipppppzp", "i"),
     "umpr_vgg16_pool5_offset": ("i", "z"),
+    "umpr_vgg16_set_block_callback": ("pp", "i"),
+    "umpr_vgg16_wgrad_stream": ("", "p"),
     "umpr_vgg16_features_fwd": ("ppippzp", "i"),
     "umpr_vgg16_classifier_fwd": ("piiiuppppzp", "i"),
     "umpr_vgg16_classifier_bwd_ws_bytes": ("i", "z"),
@@ -107,7 +109,7 @@ class _Lib:
         for name, (args, ret) in SIGNATURES.items():
             f = getattr(self.cdll, name)
             f.argtypes = [_T[c] for c in args]
-            f.restype = {"i": ctypes.c_int, "z": ctypes.c_size_t, "s": ctypes.c_char_p}[ret]
+            f.restype = {"i": ctypes.c_int, "z": ctypes.c_size_t, "s": ctypes.c_char_p, "p": ctypes.c_void_p}[ret]
             self.fn[name] = f
 
     def last_error(self) -> str:

@@ -546,7 +546,16 @@ struct WgradSide {
 };
 WgradSide g_wside;
 const bool g_wgrad_side = [] { const char* v = getenv("UMPR_WGRAD_STREAM"); return !(v && v[0] == '0'); }();
+// host callback after the kernels of one VGG block's backward have been enqueued (data parallel: the caller starts that
+// block's gradient exchange while the blocks below are still being computed)
+umpr_block_callback g_block_cb = nullptr;
+void* g_block_user = nullptr;
 }  // namespace
+
+int umpr_vgg16_set_block_callback(umpr_block_callback cb, void* user) { g_block_cb = cb; g_block_user = user; return 0; }
+void* umpr_vgg16_wgrad_stream(void) {
+  return (g_wgrad_side && g_wside.init()) ? static_cast<void*>(g_wside.stream) : nullptr;
+}
 
 int umpr_vgg16_features_bwd(const float* images, const float* const* params, int n, const float* acts,
                             const float* d_pool5, float* const* grads, float* ws, size_t ws_bytes, void* stream) {
@@ -601,6 +610,7 @@ int umpr_vgg16_features_bwd(const float* images, const float* const* params, int
         return rc;
       g = cur; gslot = (nxt + 2) % 3;
     }
+    if (g_block_cb) g_block_cb(b, g_block_user);   // every weight-gradient kernel of block b is enqueued (on sw)
     if (ci == 0 && b == 0) break;
   }
   if (side) {  // the caller's stream owns the results again: every weight gradient is complete behind this wait
@@ -800,6 +810,7 @@ int umpr_vgg16_bf16_features_bwd(const float* images, const float* const* params
                                       b16_pack_bytes(), s)) return rc;
       gs = cs;
     }
+    if (g_block_cb) g_block_cb(b, g_block_user);   // every weight-gradient kernel of block b is enqueued (on sw)
     if (ci == 0 && b == 0) break;
   }
   if (side) (void)hipStreamWaitEvent(s, g_wside.done[0], 0);   // every weight gradient is complete behind this wait

@@ -264,6 +264,28 @@ class _Control(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------- K10
+# Data parallel: callables(block) run on the host each time the feature backward has enqueued one VGG block (4 .. 0) - the
+# gradient reducer starts that block's all-reduce from there (parallel.GradReducer).  Only when the gradients are written
+# in place into the optimiser's arena, i.e. when the slice the hook exchanges really holds this step's values.
+BLOCK_HOOKS = {}     # id(first conv weight Parameter of the VGG16 being differentiated) -> callable(block)
+_BLOCK_CB_TYPE = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
+
+
+def _features_bwd_call(name, direct, params, *args):
+    hook = BLOCK_HOOKS.get(id(params[0])) if params else None
+    if hook is not None and all(direct):
+        def _cb(block, _user):
+            hook(int(block))
+        cb = _BLOCK_CB_TYPE(_cb)
+        lib().call("umpr_vgg16_set_block_callback", ctypes.cast(cb, ctypes.c_void_p), None)
+        try:
+            lib().call(name, *args)
+        finally:
+            lib().call("umpr_vgg16_set_block_callback", None, None)
+    else:
+        lib().call(name, *args)
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return arr, ctypes.cast(arr, ctypes.c_void_p)
@@ -302,7 +324,8 @@ class _VGGFeatures(torch.autograd.Function):
         ws, wsb = _ws(lib().size("umpr_vgg16_features_bwd_ws_bytes", n), dev)
         keep_p, parr = _ptr_array(params + params[:6])
         keep_g, garr = _ptr_array(grads + grads[:6])
-        lib().call("umpr_vgg16_features_bwd", images, parr, n, acts, _c(d_pool5), garr, ws, wsb, stream_ptr())
+        _features_bwd_call("umpr_vgg16_features_bwd", direct, ctx.param_objs, images, parr, n, acts, _c(d_pool5), garr, ws,
+                           wsb, stream_ptr())
         return (None, *_grad_returns(ctx.param_objs, grads, direct))
 
 
@@ -339,7 +362,8 @@ class _VGGFeaturesBF16(torch.autograd.Function):
         ws, wsb = _ws(lib().size("umpr_vgg16_bf16_bwd_ws_bytes", n), dev)
         keep_p, parr = _ptr_array(params + params[:6])
         keep_g, garr = _ptr_array(grads + grads[:6])
-        lib().call("umpr_vgg16_bf16_features_bwd", images, parr, n, acts, _c(d_pool5), garr, ws, wsb, stream_ptr())
+        _features_bwd_call("umpr_vgg16_bf16_features_bwd", direct, ctx.param_objs, images, parr, n, acts, _c(d_pool5), garr,
+                           ws, wsb, stream_ptr())
         return (None, *_grad_returns(ctx.param_objs, grads, direct))
 
 

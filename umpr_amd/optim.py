@@ -13,6 +13,11 @@ import torch
 from ._lib import lib, stream_ptr
 
 
+import os
+
+_EARLY_ADAM = os.environ.get("UMPR_EARLY_ADAM", "1") == "1"
+
+
 def _is_classifier(name):
     return name.startswith("classifier.") or ".classifier." in name
 
@@ -93,7 +98,13 @@ class FusedAdam:
                 p._umpr_fresh = True
 
     def arm_early(self, grad_scale=1.0):
-        """train_step: the coming backward belongs to exactly one optimiser step with this gradient scale."""
+        """train_step: the coming backward belongs to exactly one optimiser step with this gradient scale.
+        UMPR_EARLY_ADAM=0 turns it off.  Worth little on one GPU (the HBM-bound Adam kernel competes with the convolutions
+        it runs beside: 42.57 vs 42.44 ms) and 0.3-0.5 ms per step behind the all-reduce in the RCCL rehearsal (43.16 vs
+        43.49 ms fp32, 16.06 vs 16.51 ms bf16).  Its stream is one more next to main / text / weight-gradient / RCCL:
+        umpr_amd/__init__.py raises GPU_MAX_HW_QUEUES so that they do not share hardware queues."""
+        if not _EARLY_ADAM:
+            return
         self._early = (float(grad_scale),)
         self._early_done = None
 

@@ -119,6 +119,17 @@ class GradReducer:
         self.hooks = []
         if active() and hasattr(opt, "early_step"):
             opt.reducer = self     # the optimiser's early classifier update must follow this reducer's all-reduce
+        # per-VGG-block buckets: the conv weight gradients of block b are exchanged as soon as the feature backward has
+        # enqueued that block (model.BLOCK_HOOKS), ordered behind the library's weight-gradient stream - 60 MB that used
+        # to wait for the end of the whole backward
+        self.block_slices = self._find_block_slices() if active() else {}
+        self.reduced = []          # (lo, hi) ranges of arena 0 already handed to an all-reduce in this step
+        if self.block_slices:
+            from . import model as _model
+            g0 = opt.groups[0]
+            first = [p for n, p in zip(g0.names, g0.params) if n.endswith(".features.0.weight")]
+            if first:
+                _model.BLOCK_HOOKS[id(first[0])] = self._on_block    # keyed by THIS model's first conv weight
         if self.early is not None and active():
             self.pending = len(self.early[3])
             self.hooks = [p.register_post_accumulate_grad_hook(self._landed) for p in self.early[3]]
@@ -126,6 +137,37 @@ class GradReducer:
             for m in getattr(opt, "model", torch.nn.Module()).modules():
                 if hasattr(m, "grad_callbacks"):
                     m.grad_callbacks.append(self._written_in_place)
+
+    _VGG_BLOCK_CONVS = {0: (0, 2), 1: (5, 7), 2: (10, 12, 14), 3: (17, 19, 21), 4: (24, 26, 28)}
+
+    def _find_block_slices(self):
+        g = self.opt.groups[0] if getattr(self.opt, "groups", None) else None
+        if g is None:
+            return {}
+        out = {}
+        for b, idxs in self._VGG_BLOCK_CONVS.items():
+            names = [n for n in g.names if any(n.endswith(f".features.{i}.weight") for i in idxs)]
+            if len(names) != len(idxs):
+                return {}
+            spans = sorted(g.offsets[n] for n in names)
+            lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
+            if sum(k for _, k in spans) != hi - lo:        # not contiguous in the arena: leave it to finish()
+                return {}
+            out[b] = (lo, hi)
+        return out
+
+    def _on_block(self, block):
+        if not active() or block not in self.block_slices:
+            return
+        import contextlib
+        from ._lib import lib
+        lo, hi = self.block_slices[block]
+        arena = self.opt.groups[0].g
+        ws = lib().fn["umpr_vgg16_wgrad_stream"]() if arena.is_cuda else None
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(ws, device=arena.device)) if ws else contextlib.nullcontext()
+        with ctx:   # the collective is ordered behind the stream the block's weight-gradient kernels were issued on
+            self.handles.append(dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self.reduced.append((lo, hi))
 
     def _landed(self, _param=None):
         self.pending -= 1
@@ -159,14 +201,26 @@ class GradReducer:
                 p._umpr_fresh = False
         if self.early is not None and active() and self.hooks:
             self._fire()
+        for b in (4, 3, 2, 1, 0):
+            self._on_block(b)
 
     def finish(self):
         if not active():
             return
         arenas = self.opt.grad_arenas()
+        done = list(self.reduced)
         if self.fired:
-            arena, lo, hi, _ = self.early
-            rest = [arena[:lo], arena[hi:]] + [a for a in arenas if a.data_ptr() != arena.data_ptr()]
+            done.append((self.early[1], self.early[2]))
+        if done:   # what is left of arena 0 (the early slice and the block buckets are under way) + the other arenas
+            arena = self.early[0] if self.early is not None else self.opt.groups[0].g
+            rest, pos = [], 0
+            for lo, hi in sorted(done):
+                if lo > pos:
+                    rest.append(arena[pos:lo])
+                pos = max(pos, hi)
+            if pos < arena.numel():
+                rest.append(arena[pos:])
+            rest += [a for a in arenas if a.data_ptr() != arena.data_ptr()]
         else:
             rest = arenas
         for a in rest:
@@ -175,5 +229,6 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
+        self.reduced = []
         self.fired = False
         self.pending = len(self.early[3]) if self.hooks else 0
