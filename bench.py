@@ -348,7 +348,7 @@ def main():
                     "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
                     "traffic_note": traffic_note + "; at the measured launch time this is < 2 TB/s of HBM traffic, "
                                     "close to the compulsory activation bytes: the kernel is bound by the matrix pipe",
-                    "kernel": "conv3x3_bf16_kernel forward launches (implicit GEMM on v_mfma_f32_32x32x16_bf16, padded "
+                    "kernel": "conv3x3_bf16_kernel forward launches (implicit GEMM on v_mfma_f32_16x16x32_bf16, padded "
                               "NHWC bf16 activations); executed FLOPs = algorithmic FLOPs over the padded pixel grid",
                     "launches": n, "avg_launch_ms": ms / max(n, 1), "executed_gflop_per_launch": work / max(n, 1) / 1e9}
         else:

@@ -301,6 +301,210 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
   }
 }
 
+// The same kernel on v_mfma_f32_16x16x32_bf16: one MFMA covers the whole 32-channel chunk of a tap for a 16 px x 16 ch tile
+// (lane group l >> 4 reads plane l >> 4).  Same LDS traffic and MFMA cycles per step as the 32x32x16 form; the guide
+// measures a higher sustained clock for this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
+template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3>
+__global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf16_m16_kernel(ConvB16Params p) {
+  constexpr int ABL = 0;
+  constexpr int NW = WP * WC, NT = 64 * NW;
+  constexpr bool TWO_D = TR > 0;
+  constexpr int BM = TWO_D ? TR * TC : TC;
+  constexpr int RW = W + 1;
+  constexpr int LP = TC + 2;                      // 2-D patch row pitch (pixels)
+  constexpr int TS = TWO_D ? LP : RW;             // LDS pixels between the rows a tap's dy selects
+  constexpr int PATCH = TWO_D ? (TR + 2) * LP : BM + 2 * RW + 2;
+  constexpr int PPP = (PATCH + 63) / 64;          // DMA pieces per plane
+  constexpr int PPX = PPP * 64;                   // LDS pixels per plane
+  constexpr int PPC = 4 * PPP;                    // patch pieces per 32-channel chunk
+  constexpr int PPW = (PPC + NW - 1) / NW;        // ... per wave (surplus slots repeat a piece)
+  constexpr int WPS = BN / 16;                    // weight pieces per step (BN x 64 B)
+  constexpr int WPW = (WPS + NW - 1) / NW;
+  constexpr int NB = D + 1;                       // weights arrive D steps ahead in a ring of NB stages
+  constexpr int TPW = BM / WP / 16, TCW = BN / WC / 16;   // 16 x 16 MFMA tiles per wave
+  constexpr int WB = BN * 32, PB = 4 * PPX * 8;   // elements per weight stage / patch stage
+  static_assert(BM % (32 * WP) == 0 && BN % (32 * WC) == 0 && (!TWO_D || (W % TC == 0 && TC % 16 == 0)), "tile shape");
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[NB * WB + 2 * PB];
+  bf16_t* const Wb = smem;
+  bf16_t* const Pb = smem + NB * WB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wpx = wave / WC, wco = wave % WC;
+  const int r = lane & 15, h = lane >> 4;                 // tile row / column index and plane (k-quarter) of this lane
+
+  // XCD-aware order: workgroups b, b+8, ... share an XCD.  The weights of one output-channel tile (up to 2.4 MB) are what
+  // every pixel tile re-reads, so an XCD works on ONE channel tile where the tile count divides 8.
+  const int xcd = blockIdx.x & 7;
+  const long slot = blockIdx.x >> 3;
+  int ct; long pt;
+  if (p.nct <= 8 && (8 % p.nct) == 0) { const int g = 8 / p.nct; ct = xcd / g; pt = slot * g + (xcd % g); }
+  else { ct = (int)(slot % p.nct); pt = (slot / p.nct) * 8 + xcd; }
+  if (pt >= p.ntp) return;
+
+  long Q0; int ctile = 0;
+  if (TWO_D) {
+    constexpr int CT = W / TC;
+    const long band = pt / CT;
+    ctile = (int)(pt - band * CT);
+    Q0 = band * TR * RW + 1 + ctile * TC;
+  } else {
+    Q0 = pt * BM;
+  }
+
+  // ---- DMA plan of this wave
+  const int nchunks = p.C / 32;
+  const bf16_t* psrc[PPW]; unsigned pdst[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int q = (wave + NW * i) % PPC;
+    const int pl = q / PPP, pp = q - pl * PPP;
+    int u = pp * 64 + lane;
+    long gp;
+    if (TWO_D) {
+      if (u > PATCH - 1) u = PATCH - 1;
+      const int a = u / LP, b = u - a * LP;
+      gp = Q0 + (long)(a - 1) * RW + (b - 1);
+    } else {
+      gp = Q0 - RW - 1 + u;
+    }
+    psrc[i] = p.x + ((long)pl * p.xps + gp) * 8;
+    pdst[i] = lds_addr(Pb) + (unsigned)(pl * PPX + pp * 64) * 16u;
+  }
+  const bf16_t* wsrc[WPW]; unsigned wdst[WPW];
+  const bf16_t* wtile = p.wp + (long)ct * nchunks * 9 * WB;
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int q = (wave + NW * i) % WPS;
+    wsrc[i] = wtile + q * 512 + lane * 8;
+    wdst[i] = lds_addr(Wb) + (unsigned)q * 1024u;
+  }
+  const long chunk_stride = 4 * p.xps * 8;        // elements between 32-channel chunks of the input
+  const int S = nchunks * 9;
+  auto issue_w = [&](int s) {                     // stage of step s -> ring slot s % NB (steps past the end repeat the last)
+    const int sc = s < S ? s : S - 1;
+    const unsigned slot_off = (unsigned)(s % NB) * (WB * 2u);
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) glds16(wsrc[i] + (long)sc * WB, wdst[i] + slot_off);
+  };
+  auto issue_p = [&](int c) {                     // patch of chunk c -> buffer c & 1
+    const int cc = c < nchunks ? c : nchunks - 1;
+    const unsigned buf_off = (unsigned)(c & 1) * (PB * 2u);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(psrc[i] + cc * chunk_stride, pdst[i] + buf_off);
+  };
+
+  // ---- fragment addresses (bytes inside a stage)
+  unsigned pbo[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int k = wpx * (BM / WP) + j * 16 + r;
+    const int idx = TWO_D ? (k / TC + 1) * LP + (k % TC) + 1 : k + RW + 1;
+    pbo[j] = (unsigned)(h * PPX + idx) * 16u;
+  }
+  const unsigned wbo = (unsigned)(h * BN + wco * (BN / WC) + r) * 16u;
+
+  // accumulators start at the bias: D[cout][pixel], register x of a lane is cout 4*h + x of the 16-channel tile
+  f32x4 acc[TCW][TPW];
+#pragma unroll
+  for (int i = 0; i < TCW; ++i) {
+    f32x4 b0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) b0[x] = p.bias ? p.bias[ct * BN + wco * (BN / WC) + i * 16 + 4 * h + x] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[i][j] = b0;
+  }
+
+  issue_p(0);
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue_w(d);
+  wait_vm<(D - 1) * WPW>();
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const char* pb = reinterpret_cast<const char*>(Pb) + (c & 1) * (PB * 2);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int s = c * 9 + t;
+      if (ABL != 3) {
+        issue_w(s + D);
+        if (t == 0) issue_p(c + 1);
+      }
+      const char* wb = reinterpret_cast<const char*>(Wb) + (s % NB) * (WB * 2);
+      constexpr int dummy = 0; (void)dummy;
+      const int toff = ((t / 3) - 1) * TS + (t % 3) - 1;
+      {
+        bf16x8 a[TCW], b[TPW];
+#pragma unroll
+        for (int i = 0; i < TCW; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wb + wbo + (i * 16) * 16);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pb + pbo[j] + toff * 16);
+#pragma unroll
+        for (int i = 0; i < TCW; ++i)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      // stage s+1 (and, from the fourth step of a chunk on, the next chunk's patch) must have landed; the younger DMAs
+      // (D-1 weight stages, plus the patch while it may still fly) stay in flight across the barrier
+      if (ABL != 1 && ABL != 3) {
+        if (t < D) wait_vm<(D - 1) * WPW + PPW>(); else wait_vm<(D - 1) * WPW>();
+      }
+      if (ABL != 1) __syncthreads();
+    }
+  }
+  wait_vm<0>();
+
+  // ---- epilogue: ReLU / mask, zero at pads, bf16; a lane holds channels 4h .. 4h+3 of its pixel: 8-B stores
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int k = wpx * (BM / WP) + j * 16 + r;
+    const long P = TWO_D ? Q0 + (long)(k / TC) * RW + (k % TC) : Q0 + k;
+    if (P >= p.ptot) continue;
+    const bool real = pf_real<RW>(P, p.H);
+    bf16x4 mk[TCW];
+    if (p.mask) {
+#pragma unroll
+      for (int i = 0; i < TCW; ++i) {
+        const int co = ct * BN + wco * (BN / WC) + i * 16 + 4 * h;
+        mk[i] = *reinterpret_cast<const bf16x4*>(p.mask + ((long)(co >> 3) * p.mps + P) * 8 + (co & 7));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TCW; ++i) {
+      const int co = ct * BN + wco * (BN / WC) + i * 16 + 4 * h;
+      const long o = ((long)(co >> 3) * p.yps + P) * 8 + (co & 7);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.mask) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)mk[i][e] > 0.f ? v[e] : 0.f;
+      }
+      bf16x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = (bf16_t)(real ? v[e] : 0.f);
+      *reinterpret_cast<bf16x4*>(p.y + o) = out;
+    }
+  }
+  if (TWO_D && ctile == 0) {   // column 0 (the zero pad) of this tile's rows: no tile computes it
+    const long row0 = Q0 / RW;
+    for (int e = tid; e < TR * (BN / 8); e += NT) {
+      const int i = e % TR, cb = e / TR;
+      const long P = (row0 + i) * RW;
+      if (P < p.ptot) {
+        bf16x8 z;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) z[q] = (bf16_t)0.f;
+        *reinterpret_cast<bf16x8*>(p.y + ((long)(ct * (BN / 8) + cb) * p.yps + P) * 8) = z;
+      }
+    }
+  }
+}
+
 // packed bf16 weights from the fp32 parameter w [Cout][Cin][3][3]:
 //   wp[ct][chunk][tap][pl][m][e],  output channel o = ct*BN + m, reduction channel c = chunk*32 + pl*8 + e
 //   forward  (transposed = 0): o = cout, c = cin, value w[o][c][tap]
@@ -882,6 +1086,9 @@ inline int grid_for(long n, int cap) {
   return (int)(b < 1 ? 1 : b);
 }
 
+// 1 (default): v_mfma_f32_16x16x32_bf16 form, 5-10 % faster per layer on MI355X (profiles/r02_k_m16_ab.txt); 0: 32x32x16 form
+const int g_b16_m16 = [] { const char* v = getenv("UMPR_B16_M16"); return v ? atoi(v) : 1; }();
+
 template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3, int ABL = 0>
 void launch_conv(ConvB16Params p, hipStream_t s) {
   constexpr int BM = TR > 0 ? TR * TC : TC;
@@ -891,7 +1098,8 @@ void launch_conv(ConvB16Params p, hipStream_t s) {
   long blocks;
   if (p.nct <= 8 && (8 % p.nct) == 0) { const int g = 8 / p.nct; blocks = ((p.ntp + g - 1) / g) * 8; }
   else blocks = ((p.ntp + 7) / 8) * 8 * p.nct;
-  conv_bf16_kernel<W, TR, TC, BN, WP, WC, D, ABL><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
+  if (g_b16_m16 && ABL == 0) conv_bf16_m16_kernel<W, TR, TC, BN, WP, WC, D><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
+  else conv_bf16_kernel<W, TR, TC, BN, WP, WC, D, ABL><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
 }
 
 // tile choice per map width and output-channel count:
