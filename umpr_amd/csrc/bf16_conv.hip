@@ -720,6 +720,217 @@ __global__ __launch_bounds__(64 * WCO * WCI * KSW) void wgrad_bf16_kernel(WgradB
   }
 }
 
+// The weight gradient on v_mfma_f32_16x16x32_bf16: a k-step is 32 pixels, a wave's 32 x 32 channel tile is 2 x 2 MFMA
+// tiles per tap (same LDS bytes and MFMA cycles as the 32x32x16 form, higher sustained clock).
+template <int W, int TR, int TC, int WCO, int WCI, int KSW>
+__global__ __launch_bounds__(64 * WCO * WCI * KSW) void wgrad_bf16_m16_kernel(WgradB16Params p) {
+  constexpr int NW = WCO * WCI * KSW, NT = 64 * NW;
+  constexpr bool TWO_D = TR > 0;
+  constexpr int KP = TWO_D ? TR * TC : TC;        // pixels per segment
+  constexpr int RW = W + 1;
+  constexpr int LP = TC + 2;
+  constexpr int TS = TWO_D ? LP : RW;
+  constexpr int PATCH = TWO_D ? (TR + 2) * LP : KP + 2 * RW + 2;
+  constexpr int PPP = (PATCH + 63) / 64;
+  constexpr int PPX = PPP * 64 + 4;               // +4 pixels: plane stride off the 256-B bank period (tr reads)
+  constexpr int KPX = KP + 4;
+  constexpr int GPL = 4 * WCO, XPL = 4 * WCI;     // dY planes / x planes of the tile
+  constexpr int GPC = GPL * (KP / 64), XPC = XPL * PPP;
+  constexpr int NPC = GPC + XPC;                  // DMA pieces per segment
+  constexpr int PCW = (NPC + NW - 1) / NW;
+  constexpr int GB = GPL * KPX * 8, XB = XPL * PPX * 8;   // elements per stage
+  constexpr int KSTEPS = KP / 32, KSL = KSTEPS / KSW;
+  static_assert(KP % 64 == 0 && KSTEPS % KSW == 0 && (!TWO_D || (W % TC == 0 && TC % 16 == 0)), "segment shape");
+  constexpr int RED = KSW > 1 ? (WCO * WCI * 9 * 16 * 64 + WCO * WCI * 32) * 2 : 0;   // fp32 exchange of the wave groups, in bf16 units
+  constexpr int SMEM = 2 * (GB + XB) > RED ? 2 * (GB + XB) : RED;
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[SMEM];
+  bf16_t* const Gs = smem;                         // [2][GB]
+  bf16_t* const Xs = smem + 2 * GB;                // [2][XB]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ksw = wave / (WCO * WCI), wt = wave % (WCO * WCI);
+  const int wco = wt / WCI, wci = wt % WCI;
+  // workgroups of one split read the same pixels: keep them on one XCD (splits is a multiple of 8 or the tail idles)
+  const int xcd = blockIdx.x & 7;
+  const long qq = blockIdx.x >> 3;
+  const int tile = (int)(qq % p.ntiles);
+  const int split = (int)(qq / p.ntiles) * 8 + xcd;
+  if (split >= p.splits) return;
+  const int cot = tile / p.ncit, cit = tile % p.ncit;
+  const long sbeg = (long)split * p.segs_per_split;
+  const long send = min(p.nseg, sbeg + p.segs_per_split);
+
+  // ---- DMA plan: piece q of a segment; q < GPC: dY plane q / (KP/64), 64 pixels; else x plane, patch piece
+  const bf16_t* src0[PCW]; unsigned dst0[PCW]; int isx[PCW];
+#pragma unroll
+  for (int i = 0; i < PCW; ++i) {
+    const int q = (wave + NW * i) % NPC;
+    if (q < GPC) {
+      const int pl = q / (KP / 64), pp = q % (KP / 64);
+      const int k = pp * 64 + lane;
+      const long gp = TWO_D ? (long)(k / TC) * RW + (k % TC) : k;
+      src0[i] = p.dy + ((long)(cot * GPL + pl) * p.dps + gp) * 8;
+      dst0[i] = lds_addr(Gs) + (unsigned)(pl * KPX + pp * 64) * 16u;
+      isx[i] = 0;
+    } else {
+      const int q2 = q - GPC;
+      const int pl = q2 / PPP, pp = q2 % PPP;
+      int u = pp * 64 + lane;
+      long gp;
+      if (TWO_D) {
+        if (u > PATCH - 1) u = PATCH - 1;
+        const int a = u / LP, b = u - a * LP;
+        gp = (long)(a - 1) * RW + (b - 1);
+      } else {
+        gp = u - RW - 1;
+      }
+      src0[i] = p.x + ((long)(cit * XPL + pl) * p.xps + gp) * 8;
+      dst0[i] = lds_addr(Xs) + (unsigned)(pl * PPX + pp * 64) * 16u;
+      isx[i] = 1;
+    }
+  }
+  auto seg_origin = [&](long seg) -> long {
+    if (TWO_D) {
+      constexpr int CT = W / TC;
+      const long band = seg / CT;
+      return band * TR * RW + 1 + (seg - band * CT) * TC;
+    }
+    return seg * KP;
+  };
+  auto issue = [&](long seg, int buf) {
+    const long q0 = seg_origin(seg) * 8;
+#pragma unroll
+    for (int i = 0; i < PCW; ++i)
+      glds16(src0[i] + q0, dst0[i] + (unsigned)buf * (isx[i] ? XB * 2u : GB * 2u));
+  };
+
+  // ---- fragment addresses.  16-lane group g handles pixels 8g .. 8g+7 of the 32-pixel k-step for 16 channels (two
+  // planes); inside a group lane 4q+p supplies the address of k-row q, channels 4p..4p+3.  Wave group ksw works on the
+  // k-steps kk*KSW + ksw: its offset is part of the lane base, so every k-step / tap offset below is an immediate.
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int kg = 8 * g + q4;                                          // + 4 for the second read of a k-step
+  const int kx = ((TWO_D && TC == 16) ? (g >> 1) * LP + 8 * (g & 1) : 8 * g) + q4;
+  const int kadv_g = ksw * 32;
+  const int kadv_x = ksw * (TWO_D ? (TC == 16 ? 2 * LP : LP) : 32);
+  const unsigned abase = (unsigned)((wco * 4 + (p4 >> 1)) * KPX + kg + kadv_g) * 16u + (p4 & 1) * 8u;   // + 2 planes per tile
+  const unsigned bbase = (unsigned)((wci * 4 + (p4 >> 1)) * PPX + kx + kadv_x) * 16u + (p4 & 1) * 8u;
+
+  f32x4 acc[9][2][2];                                                  // [tap][co tile][ci tile]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) acc[t][u >> 1][u & 1][x] = 0.f;
+  // bias gradient: an A fragment of a lane is 8 pixels of ONE output channel (row l & 15 of its tile) - the waves
+  // with input-channel position 0 of the ci-tile-0 workgroups add them up on the side (16 VALU per 9 MFMAs)
+  const bool do_bias = p.bslab != nullptr && cit == 0 && wci == 0;   // wave-uniform
+  float bsum[2] = {0.f, 0.f};
+
+  if (sbeg < send) issue(sbeg, 0);
+  wait_vm<0>();
+  __syncthreads();
+  for (long seg = sbeg; seg < send; ++seg) {
+    const int cur = (int)(seg - sbeg) & 1;
+    issue(seg + 1 < send ? seg + 1 : seg, cur ^ 1);      // the last segment re-loads itself: uniform DMA count
+    const char* gs = reinterpret_cast<const char*>(Gs) + cur * (GB * 2) + abase;
+    const char* xs = reinterpret_cast<const char*>(Xs) + cur * (XB * 2) + bbase;
+#pragma unroll
+    for (int kk = 0; kk < KSL; ++kk) {
+      const int ko = kk * KSW * 32;                      // first pixel of wave group 0's k-step in the dY image
+      const int xo = TWO_D ? (ko / TC + 1) * LP + (ko % TC) + 1 : ko + RW + 1;   // ... and in the x patch (centre tap)
+      bf16x8 a[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(gs + (i * 2 * KPX + ko) * 16));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(gs + (i * 2 * KPX + ko + 4) * 16));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[i][e] = a0[e]; a[i][4 + e] = a1[e]; }
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float s4 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s4 += (float)a[i][e];
+          bsum[i] += s4;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) - 1) * TS + (t % 3) - 1;
+        bf16x8 b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(xs + (i * 2 * PPX + xo + toff) * 16));
+          const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(xs + (i * 2 * PPX + xo + toff + 4) * 16));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { b[i][e] = b0[e]; b[i][4 + e] = b1[e]; }
+        }
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib)
+            acc[t][ia][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[ib], acc[t][ia][ib], 0, 0, 0);
+      }
+    }
+    wait_vm<0>();
+    __syncthreads();
+  }
+
+  // ---- combine the KSW wave groups through LDS, then store the slab tile: D[co][ci], lanes run along ci
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                          // the four k-quarters of a channel
+    bsum[i] += __shfl_xor(bsum[i], 16, 64);
+    bsum[i] += __shfl_xor(bsum[i], 32, 64);
+  }
+  if (KSW > 1) {
+    float* red = reinterpret_cast<float*>(smem);       // [WCO*WCI][144][64] floats = 36 KB per wave, then [WCO*WCI][32]
+    if (ksw == 1) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) red[((wt * 9 + t) * 16 + u * 4 + x) * 64 + lane] = acc[t][u >> 1][u & 1][x];
+      if (lane < 16) {
+        red[WCO * WCI * 9 * 16 * 64 + wt * 32 + lane] = bsum[0];
+        red[WCO * WCI * 9 * 16 * 64 + wt * 32 + 16 + lane] = bsum[1];
+      }
+    }
+    __syncthreads();
+    if (ksw == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) acc[t][u >> 1][u & 1][x] += red[((wt * 9 + t) * 16 + u * 4 + x) * 64 + lane];
+      bsum[0] += red[WCO * WCI * 9 * 16 * 64 + wt * 32 + (lane & 15)];
+      bsum[1] += red[WCO * WCI * 9 * 16 * 64 + wt * 32 + 16 + (lane & 15)];
+    }
+  }
+  if (ksw == 0) {
+    const int r = lane & 15;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ci = cit * 32 * WCI + wci * 32 + (u & 1) * 16 + r;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int co = cot * 32 * WCO + wco * 32 + (u >> 1) * 16 + 4 * g + x;
+        float* o = p.slab + (((long)split * p.Cout + co) * p.Cin + ci) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o[t] = acc[t][u >> 1][u & 1][x];
+      }
+    }
+    if (do_bias && lane < 16) {
+      p.bslab[(long)split * p.Cout + cot * 32 * WCO + wco * 32 + lane] = bsum[0];
+      p.bslab[(long)split * p.Cout + cot * 32 * WCO + wco * 32 + 16 + lane] = bsum[1];
+    }
+  }
+}
+
 // dW (+)= sum over splits of slab[split][...] in the parameter's own order (float4), db likewise from bslab
 __global__ void wgrad_reduce_linear_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, int splits,
                                            long per, int Cout, float* __restrict__ dw, float* __restrict__ db,
@@ -1089,6 +1300,8 @@ inline int grid_for(long n, int cap) {
 // 1 (default): v_mfma_f32_16x16x32_bf16 form, 5-10 % faster per layer on MI355X (profiles/r02_k_m16_ab.txt); 0: 32x32x16 form
 const int g_b16_m16 = [] { const char* v = getenv("UMPR_B16_M16"); return v ? atoi(v) : 1; }();
 
+const int g_b16_wm16 = [] { const char* v = getenv("UMPR_B16_WM16"); return v ? atoi(v) : 1; }();   // weight gradient likewise (+2 %)
+
 template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3, int ABL = 0>
 void launch_conv(ConvB16Params p, hipStream_t s) {
   constexpr int BM = TR > 0 ? TR * TC : TC;
@@ -1162,7 +1375,8 @@ template <int W, int TR, int TC, int WCO, int WCI, int KSW>
 void launch_wgrad(WgradB16Params p, const WgradPlan& q, hipStream_t s) {
   p.nseg = q.nseg; p.ncit = q.ncit; p.ntiles = q.ntiles; p.splits = q.splits; p.segs_per_split = q.segs_per_split;
   const long blocks = (long)((q.splits + 7) / 8) * 8 * q.ntiles;
-  wgrad_bf16_kernel<W, TR, TC, WCO, WCI, KSW><<<dim3((unsigned)blocks), 64 * WCO * WCI * KSW, 0, s>>>(p);
+  if (g_b16_wm16) wgrad_bf16_m16_kernel<W, TR, TC, WCO, WCI, KSW><<<dim3((unsigned)blocks), 64 * WCO * WCI * KSW, 0, s>>>(p);
+  else wgrad_bf16_kernel<W, TR, TC, WCO, WCI, KSW><<<dim3((unsigned)blocks), 64 * WCO * WCI * KSW, 0, s>>>(p);
 }
 
 }  // namespace
