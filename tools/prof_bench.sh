@@ -6,7 +6,7 @@ tag="$1"; shift
 rm -rf /tmp/pb_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_$tag -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/${tag}_bench.jsonl 2> /tmp/pb_$tag.err || { tail -5 /tmp/pb_$tag.err; exit 1; }
 cp /tmp/pb_$tag/p_kernel_stats.csv $R/gpurun_out/${tag}_kernel_stats.csv
-python3 - /tmp/pb_$tag/p_kernel_trace.csv <<'PY'
+PB_TIMELINE=$R/gpurun_out/${tag}_timeline.txt python3 - /tmp/pb_$tag/p_kernel_trace.csv <<'PY'
 import csv, sys, collections
 # longest individual dispatches of the generic kernels (which GEMM / reduce calls carry the time)
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -56,6 +56,17 @@ if qk:
             if gap > 40000:
                 print(f"   {gap/1e3:8.1f} us  after {sh(a)}  before {sh(b)}")
         print(f"   total idle between kernels on that queue: {tot/1e6:.2f} ms")
+# timeline of the last step over all queues: start (us from the step's first dispatch), duration, queue, kernel
+import os
+if qk and len(adam) >= 2:
+    t_lo, t_hi = int(seg[0]['Start_Timestamp']) - 2000000, int(seg[-1]['End_Timestamp'])
+    prev_adam_end = int(mq[lo]['End_Timestamp']) if lo else t_lo
+    tl = sorted((r for r in rows if prev_adam_end <= int(r['Start_Timestamp']) <= t_hi), key=lambda r: int(r['Start_Timestamp']))
+    with open(os.environ.get('PB_TIMELINE', '/tmp/timeline.txt'), 'w') as f:
+        for r in tl:
+            s0, e0 = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+            n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:80]
+            f.write(f"{(s0 - prev_adam_end)/1e3:9.1f} {(e0 - s0)/1e3:8.1f} q{r[qk]} {n}\n")
 print("longest generic-kernel dispatches:")
 for r in sel[:24]:
     n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:60]

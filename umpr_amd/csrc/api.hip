@@ -663,7 +663,31 @@ VggB16Layout vgg_b16_layout(int n) {
   L.total = off;
   return L;
 }
-size_t b16_pack_bytes() { return align_up(umpr_conv_bf16_pack_bytes(512, 512), 1024); }
+// packed weights of the 12 MFMA layers (conv index 1..12), one region each
+struct B16Packs { size_t off[13]; size_t total; };
+B16Packs b16_packs() {
+  B16Packs P;
+  size_t off = 0;
+  int cin = 64, ci = 1;
+  P.off[0] = 0;
+  for (int b = 0; b < 5; ++b)
+    for (int j = (b == 0 ? 1 : 0); j < kConvPerBlock[b]; ++j, ++ci) {
+      P.off[ci] = off;
+      off += align_up(umpr_conv_bf16_pack_bytes(cin, kBlockCh[b]), 1024);
+      cin = kBlockCh[b];
+    }
+  P.total = off;
+  return P;
+}
+size_t b16_pack_bytes() { return b16_packs().total; }
+int b16_pack_all(const VggB16Layout& L, const float* const* params, int transposed, void* wpack, hipStream_t s) {
+  const B16Packs P = b16_packs();
+  const float* w[12]; int cin[12], cout[12], width[12];
+  for (int ci = 1; ci < 13; ++ci) {
+    w[ci - 1] = params[2 * ci]; cin[ci - 1] = L.conv_cin[ci]; cout[ci - 1] = L.conv_cout[ci]; width[ci - 1] = L.geo[L.conv_block[ci]].W;
+  }
+  return umpr_conv_bf16_pack_all(w, cin, cout, width, 12, transposed, wpack, P.off + 1, s);
+}
 size_t b16_wgrad_ws_bytes(int n) {
   const VggB16Layout L = vgg_b16_layout(n);
   size_t m = umpr_conv1_bf16_wgrad_ws_bytes();
@@ -735,6 +759,8 @@ int umpr_vgg16_bf16_features_fwd(const float* images, const float* const* params
     for (int b = 0; b < 5; ++b) { bases[13 + b] = BP(acts) + L.pool_off[b]; geos[13 + b] = L.pool_geo[b]; ch[13 + b] = kBlockCh[b]; }
     if (int rc = umpr_pf_zero_guards_multi(bases, geos, ch, 18, s)) return rc;
   }
+  const B16Packs PK = b16_packs();
+  if (int rc = b16_pack_all(L, params, 0, wpack, s)) return rc;
   // first layer (3 input channels, K = 27 padded to 32): its own kernel, fp32 image in, bf16 CB8-PF out
   if (int rc = umpr_conv1_bf16_fwd(images, params[0], params[1], BP(acts) + L.conv_off[0], L.geo[0], s, false)) return rc;
   const void* x = BP(acts) + L.conv_off[0];
@@ -742,8 +768,8 @@ int umpr_vgg16_bf16_features_fwd(const float* images, const float* const* params
   for (int b = 0; b < 5; ++b) {
     for (int j = (b == 0 ? 1 : 0); j < kConvPerBlock[b]; ++j, ++ci) {
       void* y = BP(acts) + L.conv_off[ci];
-      if (int rc = umpr_conv_bf16_run(x, params[2 * ci], 0, params[2 * ci + 1], nullptr, y, L.geo[b], L.conv_cin[ci],
-                                      L.conv_cout[ci], 1, wpack, b16_pack_bytes(), s, false)) return rc;
+      if (int rc = umpr_conv_bf16_run(x, nullptr, 0, params[2 * ci + 1], nullptr, y, L.geo[b], L.conv_cin[ci],
+                                      L.conv_cout[ci], 1, BP(wpack) + PK.off[ci], PK.total - PK.off[ci], s, false)) return rc;
       x = y;
     }
     void* y = BP(acts) + L.pool_off[b];
@@ -774,6 +800,8 @@ int umpr_vgg16_bf16_features_bwd(const float* images, const float* const* params
     if (side && slot_reader[k] >= 0) { (void)hipStreamWaitEvent(s, g_wside.done[slot_reader[k]], 0); slot_reader[k] = -1; }
     return k;
   };
+  const B16Packs PK = b16_packs();
+  if (int rc = b16_pack_all(L, params, 1, wpack, s)) return rc;
   // gradient w.r.t. the pooled 7x7 map arrives in fp32 NCHW order from the classifier
   int gs = claim();
   if (int rc = umpr_nchw_to_cb8(d_pool5, buf[gs], L.pool_geo[4], 512, s)) return rc;
@@ -806,8 +834,8 @@ int umpr_vgg16_bf16_features_bwd(const float* images, const float* const* params
       // the input came straight from a conv+ReLU (j > 0): mask by it; from a pool (j == 0): the pool backward masks
       const void* mask = j > 0 ? xin : nullptr;
       cs = claim();
-      if (int rc = umpr_conv_bf16_run(buf[gs], params[2 * ci], 1, nullptr, mask, buf[cs], L.geo[b], cin, cout, 0, wpack,
-                                      b16_pack_bytes(), s)) return rc;
+      if (int rc = umpr_conv_bf16_run(buf[gs], nullptr, 1, nullptr, mask, buf[cs], L.geo[b], cin, cout, 0,
+                                      BP(wpack) + PK.off[ci], PK.total - PK.off[ci], s)) return rc;
       gs = cs;
     }
     if (g_block_cb) g_block_cb(b, g_block_user);   // every weight-gradient kernel of block b is enqueued (on sw)

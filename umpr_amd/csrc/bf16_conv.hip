@@ -527,6 +527,29 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, bf16_t* __
   }
 }
 
+// the same for up to 12 layers in one launch (all packs of a forward or a backward pass): blockIdx.y = layer
+struct PackSet { const float* w[12]; bf16_t* wp[12]; int M[12], C[12], Cin[12], BN[12]; int transposed, n; };
+__global__ void pack_weights_bf16_multi_kernel(PackSet ps) {
+  const int l = blockIdx.y;
+  const float* __restrict__ w = ps.w[l];
+  bf16_t* __restrict__ wp = ps.wp[l];
+  const int M = ps.M[l], C = ps.C[l], Cin = ps.Cin[l], BN = ps.BN[l];
+  const long total = (long)M * C * 9;
+  const int nchunks = C / 32;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 7);
+    long q = idx >> 3;
+    const int m = (int)(q % BN); q /= BN;
+    const int pl = (int)(q & 3); q >>= 2;
+    const int tap = (int)(q % 9); q /= 9;
+    const int chunk = (int)(q % nchunks);
+    const int ct = (int)(q / nchunks);
+    const int o = ct * BN + m, c = chunk * 32 + pl * 8 + e;
+    const float v = ps.transposed ? w[((long)c * Cin + o) * 9 + 8 - tap] : w[((long)o * Cin + c) * 9 + tap];
+    wp[idx] = (bf16_t)v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // weight gradient
 struct WgradB16Params {
@@ -1387,6 +1410,25 @@ size_t umpr_conv_bf16_pack_bytes(int Cin, int Cout) { return (size_t)Cin * Cout 
 // forward (transposed = 0): y[M = Cout] = relu?(conv(x[C = Cin]) + bias);  dgrad (transposed = 1): y[M = Cin] =
 // conv^T(x[C = Cout]) * [mask > 0].  x, y, mask: pointers to the START of plane 0 (incl. the lead guard) of CB8-PF
 // tensors of geometry g.  wpack: scratch of umpr_conv_bf16_pack_bytes.  The output's guards are zeroed here.
+
+// packs the weights of n (<= 12) layers in one launch: layer i -> wpack + offsets[i] (each umpr_conv_bf16_pack_bytes
+// apart at least), in the tile order umpr_conv_bf16_run picks for a W[i] x W[i] map
+int umpr_conv_bf16_pack_all(const float* const* w, const int* Cin, const int* Cout, const int* W, int n, int transposed,
+                            void* wpack, const size_t* offsets, hipStream_t s) {
+  UMPR_REQUIRE(n >= 1 && n <= 12, "conv_bf16_pack_all: %d layers", n);
+  PackSet ps;
+  ps.n = n; ps.transposed = transposed;
+  for (int i = 0; i < n; ++i) {
+    const int M = transposed ? Cin[i] : Cout[i], C = transposed ? Cout[i] : Cin[i];
+    UMPR_REQUIRE(C % 32 == 0 && M % 64 == 0, "conv_bf16_pack_all: channels (%d -> %d)", C, M);
+    ps.w[i] = w[i]; ps.wp[i] = reinterpret_cast<bf16_t*>(static_cast<char*>(wpack) + offsets[i]);
+    ps.M[i] = M; ps.C[i] = C; ps.Cin[i] = Cin[i]; ps.BN[i] = conv_bn_for(M, W[i]);
+  }
+  pack_weights_bf16_multi_kernel<<<dim3(128, n), 256, 0, s>>>(ps);
+  UMPR_LAUNCH_CHECK("pack_weights_bf16_multi");
+  return 0;
+}
+
 int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const float* bias, const void* mask, void* y,
                        const UmprPF& g, int Cin, int Cout, int relu, void* wpack, size_t wpack_bytes, hipStream_t s,
                        bool zero_guards) {
@@ -1397,8 +1439,10 @@ int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const floa
   UMPR_REQUIRE(wpack_bytes >= umpr_conv_bf16_pack_bytes(Cin, Cout), "conv_bf16: weight scratch too small");
   const int BN = conv_bn_for(M, g.W);
   bf16_t* wp = static_cast<bf16_t*>(wpack);
-  pack_weights_bf16_kernel<<<grid_for((long)M * C * 9, 2048), 256, 0, s>>>(w, wp, M, C, Cin, BN, transposed);
-  UMPR_LAUNCH_CHECK("pack_weights_bf16");
+  if (w) {   // w == nullptr: wpack already holds this layer's packed weights (umpr_conv_bf16_pack_all)
+    pack_weights_bf16_kernel<<<grid_for((long)M * C * 9, 2048), 256, 0, s>>>(w, wp, M, C, Cin, BN, transposed);
+    UMPR_LAUNCH_CHECK("pack_weights_bf16");
+  }
   bf16_t* y0 = static_cast<bf16_t*>(y);
   if (zero_guards) {
     zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), M / 8), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);

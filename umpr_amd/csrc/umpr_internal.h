@@ -90,6 +90,8 @@ size_t umpr_conv_bf16_pack_bytes(int Cin, int Cout);
 int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const float* bias, const void* mask, void* y,
                        const UmprPF& g, int Cin, int Cout, int relu, void* wpack, size_t wpack_bytes, hipStream_t s,
                        bool zero_guards = true);
+int umpr_conv_bf16_pack_all(const float* const* w, const int* Cin, const int* Cout, const int* W, int n, int transposed,
+                            void* wpack, const size_t* offsets, hipStream_t s);
 int umpr_pf_zero_guards_multi(void* const* bases, const UmprPF* geos, const int* channels, int n, hipStream_t s);
 size_t umpr_wgrad_bf16_ws_bytes(const UmprPF& g, int Cin, int Cout);
 int umpr_wgrad_bf16_run(const void* dy, const void* x, float* dw, float* db, const UmprPF& g, int Cin, int Cout,

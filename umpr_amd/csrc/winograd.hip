@@ -547,9 +547,45 @@ size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W) {
   return (size_t)16 * (MT * WBM * S * WK + S * WK * Tpad + MT * WBM * Tpad) + 64;
 }
 
+// Image chunking: V and M (each 4x the activation they transform) are written by one kernel and read back by the next.
+// With the whole batch in one pass (411 MB + 822 MB at 56x56x128->256, batch 64) every one of those bytes goes to HBM and
+// comes back; a chunk whose V + M stay under the 256 MiB Infinity Cache is re-read on die
+// (MI355X_MICROARCH.md, Infinity Cache: a line stays resident while the bytes touched between two uses fit).
+// UMPR_WINO_CHUNK_MB = budget for V + M of one chunk (0 = whole batch in one pass, the default).
+// Measured (batch 64, fp32 step): 0 -> 42.5 ms, 224 -> 45.3, 160 -> 46.5, 96 -> 50.7: the smaller GEMMs and the extra
+// launches cost more than on-die re-reads give back, so it stays an experiment switch (profiles/README.md, r02_n).
+static const long g_wino_chunk_mb = [] { const char* v = getenv("UMPR_WINO_CHUNK_MB"); return v ? atol(v) : 0L; }();
+static int wino_chunk_images(int N, long floats_per_image) {
+  if (g_wino_chunk_mb <= 0) return N;
+  long nc = (g_wino_chunk_mb << 20) / (floats_per_image * 4);
+  if (nc < 1) nc = 1;
+  if (nc >= N) return N;
+  const int parts = (int)((N + nc - 1) / nc);          // equal parts: no small tail chunk
+  return (N + parts - 1) / parts;
+}
+
+static int wino_conv3x3_pass(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
+                             int N, int Cin, int Cout, int H, int W, int relu, float* ws, size_t ws_floats, hipStream_t s,
+                             bool weights_ready);
+
 // forward (transposed = 0) or data gradient (transposed = 1), same contract as umpr_conv3x3_run
 int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
                       int N, int Cin, int Cout, int H, int W, int relu, float* ws, size_t ws_floats, hipStream_t s) {
+  const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
+  UMPR_REQUIRE(ws_floats >= umpr_wino_ws_floats(N, C, M, H, W), "winograd: workspace too small");
+  const int nc = wino_chunk_images(N, (long)16 * (C + M) * (H / 2) * (W / 2));
+  for (int n0 = 0; n0 < N; n0 += nc) {
+    const int n = N - n0 < nc ? N - n0 : nc;
+    // U sits at the start of the workspace and does not depend on the chunk size: transformed once
+    if (int rc = wino_conv3x3_pass(x + (size_t)n0 * C * H * W, w, transposed, bias, mask ? mask + (size_t)n0 * M * H * W : nullptr,
+                                   y + (size_t)n0 * M * H * W, n, Cin, Cout, H, W, relu, ws, ws_floats, s, n0 > 0)) return rc;
+  }
+  return 0;
+}
+
+static int wino_conv3x3_pass(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
+                             int N, int Cin, int Cout, int H, int W, int relu, float* ws, size_t ws_floats, hipStream_t s,
+                             bool weights_ready) {
   UMPR_REQUIRE((H % 2) == 0 && (W % 2) == 0, "winograd: odd map %dx%d", H, W);
   const int M = transposed ? Cin : Cout;
   const int C = transposed ? Cout : Cin;
@@ -560,8 +596,10 @@ int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const floa
   float* U = ws;
   float* V = U + (size_t)16 * MT * WBM * S * WK;
   float* Mx = V + (size_t)16 * S * WK * Tpad;
-  wino_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
-  UMPR_LAUNCH_CHECK("wino_weights");
+  if (!weights_ready) {
+    wino_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
+    UMPR_LAUNCH_CHECK("wino_weights");
+  }
   const long TT = (T + WBN - 1) / WBN;
   if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)S * WK * TT * WBN / 2, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
@@ -891,8 +929,23 @@ size_t umpr_wino_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W) {
   return (size_t)16 * ((size_t)g.Mpad * g.Tpad + (size_t)g.Cpad * g.Tpad + (size_t)g.splits * g.Mpad * g.Cpad) + 64;
 }
 
+static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
+                           int accumulate, float* ws, size_t ws_floats, hipStream_t s);
+
 int umpr_wino_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
                     int accumulate, float* ws, size_t ws_floats, hipStream_t s) {
+  UMPR_REQUIRE(ws_floats >= umpr_wino_wgrad_ws_floats(N, Cin, Cout, H, W), "winograd wgrad: workspace too small");
+  const int nc = wino_chunk_images(N, (long)16 * (Cin + Cout) * (H / 2) * (W / 2));
+  for (int n0 = 0; n0 < N; n0 += nc) {   // chunks accumulate in image order: fixed summation order
+    const int n = N - n0 < nc ? N - n0 : nc;
+    if (int rc = wino_wgrad_pass(dy + (size_t)n0 * Cout * H * W, x + (size_t)n0 * Cin * H * W, dw, db, n, Cin, Cout, H, W,
+                                 accumulate || n0 > 0, ws, ws_floats, s)) return rc;
+  }
+  return 0;
+}
+
+static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
+                           int accumulate, float* ws, size_t ws_floats, hipStream_t s) {
   UMPR_REQUIRE((H % 2) == 0 && (W % 2) == 0, "winograd wgrad: odd map %dx%d", H, W);
   UMPR_REQUIRE(ws_floats >= umpr_wino_wgrad_ws_floats(N, Cin, Cout, H, W), "winograd wgrad: workspace too small");
   const WinoWgradGeom g = wino_wgrad_geom(N, Cin, Cout, H, W);
