@@ -280,6 +280,287 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
     bs[e] = ((DG[e] + DG[2 * G3 + e]) + DG[4 * G3 + e]) + DG[6 * G3 + e];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// 16-sequence tiles on v_mfma_f32_16x16x4_f32 (the default).  One workgroup = 16 sequences x one direction, 4 waves,
+// wave w owns hidden units 16w..16w+15 of all three gates.  Four times as many workgroups as the 64-sequence kernels
+// above (N = 2560 sentences: 320 instead of 80), W_hh lives in registers for the whole sequence (48 VGPRs per lane:
+// it is the same for every step), the hidden state is double-buffered in LDS (one barrier per step) and the next
+// step's gx / saved gates are loaded while the current step's MFMAs run.
+//   A lane l -> A[row = l&15][k-group l>>4], B lane l -> B[k-group l>>4][col = l&15], D reg r -> D[row = 4*(l>>4)+r][col = l&15].
+// The k index a lane group feeds in k-step kk is free as long as A and B agree: group g takes k = 16g + kk (forward)
+// so that a lane's 16 values of H / W_hh are contiguous (ds_read_b128 / float4 loads).
+constexpr int TS2 = 16;
+constexpr int LDH2 = 68;    // Hs[seq][LDH2]: 16 lanes x b128 at stride 68 floats touch 64 distinct banks
+constexpr int LDG2 = 196;   // DGs[seq][LDG2]
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void gru_fwd16_kernel(GruFwdParams p) {
+  __shared__ __attribute__((aligned(16))) float Hs[2][TS2 * LDH2];
+  __shared__ int s_n[TS2], s_len[TS2], s_dst[TS2];
+  __shared__ int s_maxlen;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int dir = blockIdx.y, tile = blockIdx.x;
+
+  if (tid == 0) s_maxlen = 0;
+  __syncthreads();
+  if (tid < TS2) {
+    const int pos = tile * TS2 + tid;
+    int n = -1, len = 0, dst = 0;
+    if (pos < p.N) {
+      n = p.order[pos];
+      len = p.lengths[n];
+      if (len > p.L) len = p.L;
+      dst = p.dst_row[n];
+    }
+    s_n[tid] = n; s_len[tid] = len; s_dst[tid] = dst;
+    atomicMax(&s_maxlen, len);
+  }
+  for (int e = tid; e < 2 * TS2 * LDH2; e += 256) (&Hs[0][0])[e] = 0.f;
+  const int hid = wave * 16 + c;
+  float w[3][16];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const float4* src = reinterpret_cast<const float4*>(p.whh[dir] + (long)(q * H + hid) * H + 16 * g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = src[i];
+      w[q][4 * i] = v.x; w[q][4 * i + 1] = v.y; w[q][4 * i + 2] = v.z; w[q][4 * i + 3] = v.w;
+    }
+  }
+  float bh[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) bh[q] = p.bhh[dir][q * H + hid];
+  __syncthreads();
+  const int maxlen = s_maxlen;
+  float hreg[4];
+  int nreg[4], lreg[4], dreg[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    hreg[r] = 0.f;
+    nreg[r] = s_n[4 * g + r]; lreg[r] = s_len[4 * g + r]; dreg[r] = s_dst[4 * g + r];
+  }
+  auto load_gx = [&](int t, float (&dst)[3][4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // unconditional (clamped) loads: a per-lane `act ? load : 0` makes hipcc branch and wait per load
+      const bool act = t >= 0 && t < lreg[r];
+      const float* gp = p.gx + (act ? ((long)nreg[r] * p.L + t) * 384 + dir * G3 + hid : 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) dst[q][r] = gp[q * H];
+    }
+  };
+  float gxn[3][4];
+  load_gx(dir == 0 ? 0 : maxlen - 1, gxn);
+
+  for (int step = 0; step < maxlen; ++step) {
+    const int t = dir == 0 ? step : maxlen - 1 - step;
+    const int tn = step + 1 < maxlen ? (dir == 0 ? t + 1 : t - 1) : -1;
+    float gxr[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gxr[q][r] = gxn[q][r];
+    load_gx(tn, gxn);                                   // in flight under this step's MFMAs
+    const float* hs = Hs[step & 1];
+    float av[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(hs + c * LDH2 + 16 * g + 4 * i);
+      av[4 * i] = v.x; av[4 * i + 1] = v.y; av[4 * i + 2] = v.z; av[4 * i + 3] = v.w;
+    }
+    f32x4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] = bh[q];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = mfma16(av[kk], w[q][kk], acc[q]);
+    float* hn_s = Hs[(step + 1) & 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = t < lreg[r];
+      if (act) {
+        const float rr = sigmoidf_(gxr[0][r] + acc[0][r]);
+        const float zz = sigmoidf_(gxr[1][r] + acc[1][r]);
+        const float hn = acc[2][r];
+        const float nn = tanhf(gxr[2][r] + rr * hn);
+        const float hnew = (1.f - zz) * nn + zz * hreg[r];
+        hreg[r] = hnew;
+        p.out[((long)dreg[r] * p.L + t) * 128 + dir * H + hid] = hnew;
+        if (p.saved) {
+          float* sv = p.saved + ((((long)dir * p.N + nreg[r]) * p.L + t) * 4) * H + hid;
+          sv[0] = rr; sv[H] = zz; sv[2 * H] = nn; sv[3 * H] = hn;
+        }
+      }
+      hn_s[(4 * g + r) * LDH2 + hid] = hreg[r];         // inactive rows carry their state into the other buffer
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_bwd16_kernel(GruBwdParams p) {
+  __shared__ __attribute__((aligned(16))) float DGs[2][TS2 * LDG2];   // dgh[seq][gate]
+  __shared__ __attribute__((aligned(16))) float HPs[2][TS2 * LDH2];   // h_prev[seq][hid]
+  __shared__ int s_n[TS2], s_len[TS2], s_dst[TS2];
+  __shared__ int s_maxlen;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int dir = blockIdx.y, tile = blockIdx.x;
+
+  if (tid == 0) s_maxlen = 0;
+  __syncthreads();
+  if (tid < TS2) {
+    const int pos = tile * TS2 + tid;
+    int n = -1, len = 0, dst = 0;
+    if (pos < p.N) {
+      n = p.order[pos];
+      len = p.lengths[n];
+      if (len > p.L) len = p.L;
+      dst = p.dst_row[n];
+    }
+    s_n[tid] = n; s_len[tid] = len; s_dst[tid] = dst;
+    atomicMax(&s_maxlen, len);
+  }
+  const int hid = wave * 16 + c;
+  // dh_prev[seq][hid] = sum_j dgh[seq][j] W_hh[j][hid]: lane group g takes j = 48g + kk, its 48 weights stay in registers
+  float w1[48];
+#pragma unroll
+  for (int kk = 0; kk < 48; ++kk) w1[kk] = p.whh[dir][(long)(48 * g + kk) * H + hid];
+  __syncthreads();
+  const int maxlen = s_maxlen;
+  float dh[4];
+  int nreg[4], lreg[4], dreg[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    dh[r] = 0.f;
+    nreg[r] = s_n[4 * g + r]; lreg[r] = s_len[4 * g + r]; dreg[r] = s_dst[4 * g + r];
+  }
+  // dW_hh[j][hid'] += sum_seq dgh[seq][j] h_prev[seq][hid'], computed transposed: rows hid' (tile ht), columns this
+  // wave's j = q*64 + hid; k-step kk of group g is sequence 4g + kk = the row this lane computed itself (register kk)
+  f32x4 accw[3][4];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) accw[q][ht][r] = 0.f;
+  float sbi[3] = {0.f, 0.f, 0.f}, sbh[3] = {0.f, 0.f, 0.f};
+
+  struct StepLoads { float ldo[4], lhp[4], lsv[4][4]; };
+  auto load_step = [&](int t, int tp, StepLoads& d) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = t >= 0 && t < lreg[r];
+      const bool hasp = act && tp >= 0 && tp < lreg[r];
+      const long orow = ((long)dreg[r] * p.L) * 128 + dir * H + hid;
+      d.ldo[r] = p.dout[act ? orow + (long)t * 128 : 0];
+      d.lhp[r] = p.out[hasp ? orow + (long)tp * 128 : 0];
+      const float* sv = p.saved + (act ? ((((long)dir * p.N + nreg[r]) * p.L + t) * 4) * H + hid : 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d.lsv[q][r] = sv[q * H];
+    }
+  };
+  StepLoads nx;
+  {
+    const int t0 = dir == 0 ? maxlen - 1 : 0;
+    load_step(maxlen > 0 ? t0 : -1, dir == 0 ? t0 - 1 : t0 + 1, nx);
+  }
+
+  for (int step = 0; step < maxlen; ++step) {
+    // reverse of the forward order
+    const int t = dir == 0 ? maxlen - 1 - step : step;
+    const int tp = dir == 0 ? t - 1 : t + 1;
+    const StepLoads cur = nx;
+    {
+      const int t2 = step + 1 < maxlen ? (dir == 0 ? t - 1 : t + 1) : -1;
+      load_step(t2, dir == 0 ? t2 - 1 : t2 + 1, nx);
+    }
+    float* dgs = DGs[step & 1];
+    float* hps = HPs[step & 1];
+    float dcarry[4], dv[3][4], hpv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = t < lreg[r];
+      const bool hasp = act && tp >= 0 && tp < lreg[r];
+      float drp = 0.f, dzp = 0.f, dghn = 0.f;
+      const float hp = hasp ? cur.lhp[r] : 0.f;
+      dcarry[r] = dh[r];
+      if (act) {
+        const float dtot = dh[r] + cur.ldo[r];
+        const float rr = cur.lsv[0][r], zz = cur.lsv[1][r], nn = cur.lsv[2][r], hn = cur.lsv[3][r];
+        const float dnp = dtot * (1.f - zz) * (1.f - nn * nn);
+        dzp = dtot * (hp - nn) * zz * (1.f - zz);
+        drp = dnp * hn * rr * (1.f - rr);
+        dghn = dnp * rr;
+        float* gp = p.dgx + ((long)nreg[r] * p.L + t) * 384 + dir * G3 + hid;
+        gp[0] = drp; gp[H] = dzp; gp[2 * H] = dnp;
+        dcarry[r] = dtot * zz;
+        sbi[0] += drp; sbi[1] += dzp; sbi[2] += dnp;
+        sbh[0] += drp; sbh[1] += dzp; sbh[2] += dghn;
+      }
+      dv[0][r] = drp; dv[1][r] = dzp; dv[2][r] = dghn; hpv[r] = hp;
+      float* row = dgs + (4 * g + r) * LDG2 + hid;
+      row[0] = drp; row[H] = dzp; row[2 * H] = dghn;
+      hps[(4 * g + r) * LDH2 + hid] = hp;
+    }
+    __syncthreads();
+    // dh_prev: three accumulator chains over j = 48g + kk
+    f32x4 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(dgs + c * LDG2 + 48 * g + 4 * i);
+      acc[0] = mfma16(v.x, w1[4 * i], acc[0]);
+      acc[1] = mfma16(v.y, w1[4 * i + 1], acc[1]);
+      acc[2] = mfma16(v.z, w1[4 * i + 2], acc[2]);
+      acc[0] = mfma16(v.w, w1[4 * i + 3], acc[0]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[r] = dcarry[r] + ((acc[0][r] + acc[1][r]) + acc[2][r]);  // inactive rows: acc = 0
+    // dW_hh
+#pragma unroll
+    for (int ht = 0; ht < 4; ++ht) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float a = hps[(4 * g + kk) * LDH2 + 16 * ht + c];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) accw[q][ht] = mfma16(a, dv[q][kk], accw[q][ht]);
+      }
+    }
+    // no second barrier: the next step writes the other DGs / HPs buffer, and the step after that is behind the
+    // next step's barrier, which every wave reaches only after these reads
+  }
+
+  float* slab = p.dwhh_slab + ((long)tile * 2 + dir) * G3 * H;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(long)(q * H + hid) * H + 16 * ht + 4 * g + r] = accw[q][ht][r];
+  // bias gradients: the four lane groups hold partial sums (4 sequences each) of the same (gate, hid): fixed-order sum
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    sbi[q] += __shfl_xor(sbi[q], 16, 64); sbi[q] += __shfl_xor(sbi[q], 32, 64);
+    sbh[q] += __shfl_xor(sbh[q], 16, 64); sbh[q] += __shfl_xor(sbh[q], 32, 64);
+  }
+  if (g == 0) {
+    float* bs = p.dbias_slab + ((long)tile * 2 + dir) * 2 * G3;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { bs[q * H + hid] = sbi[q]; bs[G3 + q * H + hid] = sbh[q]; }
+  }
+}
+
 // dst[j] (+)= sum_i src[i][j]   (rows x cols, fixed order)
 __global__ void colsum_rows_kernel(const float* __restrict__ src, int rows, long cols, long row_stride,
                                    float* __restrict__ dst, int accumulate) {
@@ -307,6 +588,9 @@ int umpr_colsum_rows(const float* src, int rows, long cols, long row_stride, flo
   return 0;
 }
 
+// UMPR_GRU_V1=1: the 64-sequence kernels (A/B runs)
+static const bool g_gru_v1 = [] { const char* v = getenv("UMPR_GRU_V1"); return v && v[0] == '1'; }();
+
 int umpr_gru_recurrent_fwd(const float* gx, const float* whh_f, const float* bhh_f, const float* whh_r,
                            const float* bhh_r, const int* lengths, const int* order, const int* dst_row, float* out,
                            float* saved, int N, int L, hipStream_t s) {
@@ -317,16 +601,17 @@ int umpr_gru_recurrent_fwd(const float* gx, const float* whh_f, const float* bhh
     umpr_set_error("gru_fwd: memset failed");
     return -2;
   }
-  dim3 grid(cdiv(N, TS), 2);
+  dim3 grid(umpr_gru_tiles(N), 2);
   // family 3 counts BYTES (HBM/latency-bound kernel): per token and both directions gx 384 floats read, out 128
   // written, saved gates 2*4*64 written when training
   UmprProfScope prof(UMPR_K_GRU, 4.0 * N * L * (384 + 128 + (saved ? 512 : 0)), s);
-  gru_fwd_kernel<<<grid, 256, 0, s>>>(p);
+  if (g_gru_v1) gru_fwd_kernel<<<grid, 256, 0, s>>>(p);
+  else gru_fwd16_kernel<<<grid, 256, 0, s>>>(p);
   UMPR_LAUNCH_CHECK("gru_fwd");
   return 0;
 }
 
-int umpr_gru_tiles(int N) { return cdiv(N, TS); }
+int umpr_gru_tiles(int N) { return cdiv(N, g_gru_v1 ? TS : TS2); }
 
 int umpr_gru_bptt(const float* dout, const float* out, const float* saved, const float* whh_f, const float* whh_r,
                   const int* lengths, const int* order, const int* dst_row, float* dgx, float* dwhh_slab,
@@ -339,10 +624,11 @@ int umpr_gru_bptt(const float* dout, const float* out, const float* saved, const
     umpr_set_error("gru_bwd: memset failed");
     return -2;
   }
-  dim3 grid(cdiv(N, TS), 2);
+  dim3 grid(umpr_gru_tiles(N), 2);
   // bytes per token: dout 128 + out 128 + saved 512 read, dgx 384 written
   UmprProfScope prof(UMPR_K_GRU, 4.0 * N * L * (128 + 128 + 512 + 384), s);
-  gru_bwd_kernel<<<grid, 256, 0, s>>>(p);
+  if (g_gru_v1) gru_bwd_kernel<<<grid, 256, 0, s>>>(p);
+  else gru_bwd16_kernel<<<grid, 256, 0, s>>>(p);
   UMPR_LAUNCH_CHECK("gru_bwd");
   return 0;
 }
