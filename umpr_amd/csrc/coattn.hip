@@ -12,14 +12,13 @@
 namespace {
 
 constexpr int D = 128;   // 2 * gru_size
-constexpr int LDT = 65;  // Ts[c][LDT], Us[c][LDT]
 
 struct ScoreParams {
   const float* T;   // [B][SL][128] = G_i M
   const float* Gu;  // [B][SL][128]
-  float* rowmax; int* argrow;        // [B][SL]
+  float* rowmax_part; int* argrow_part;  // [B][ksplit][SL]: maxima over the column tiles of one split
   float* colmax_part; int* argcol_part;  // [B][nblk][SL]
-  int SL, nblk;
+  int SL, nblk, ksplit;                  // grid (nblk row blocks, B, ksplit): column tiles are dealt out over blockIdx.z
 };
 
 __device__ __forceinline__ void better_first(float& v, int& i, float v2, int i2) {
@@ -27,9 +26,34 @@ __device__ __forceinline__ void better_first(float& v, int& i, float v2, int i2)
   if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
 }
 
+// 64 rows x 128 columns of src (rows past SL as zeros) -> dst[row][LDR], row-major: float4 in, float4 out.  All eight
+// loads of a thread are issued before the first is used, with clamped row addresses: a per-lane `valid ? load : 0`
+// makes hipcc wait for each load inside its branch (one global round trip per element, ~15 us per tile).
+constexpr int LDR = 132;   // 16 lanes x ds_read_b128 at a row stride of 132 floats touch 64 distinct banks
+__device__ __forceinline__ void stage_tile_f32(const float* __restrict__ src, int row0, int SL, float* __restrict__ dst,
+                                               int tid) {
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + 256 * i;
+    const int j = e >> 5, c4 = (e & 31) * 4;
+    v[i] = *reinterpret_cast<const float4*>(src + (long)min(row0 + j, SL - 1) * D + c4);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + 256 * i;
+    const int j = e >> 5, c4 = (e & 31) * 4;
+    *reinterpret_cast<float4*>(dst + j * LDR + c4) = row0 + j < SL ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// One workgroup = 64 rows (j) x the column tiles of its split.  Wave (wi, wu) owns a 32 x 32 tile; lane half kh takes
+// the reduction columns c = 64 kh + kk (any split of the 128 columns works as long as A and B agree), so a lane's 64
+// operand values per matrix are contiguous: 16 ds_read_b128 each, all in registers before the 64 MFMAs, which run as
+// two independent accumulator chains.
 __global__ __launch_bounds__(256) void coattn_scores_kernel(ScoreParams p) {
-  __shared__ float Ts[D * LDT];
-  __shared__ float Us[D * LDT];
+  __shared__ __attribute__((aligned(16))) float Ts[64 * LDR];
+  __shared__ __attribute__((aligned(16))) float Us[64 * LDR];
   __shared__ float xv[2][64]; __shared__ int xi[2][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wu = wave & 1;
@@ -40,30 +64,35 @@ __global__ __launch_bounds__(256) void coattn_scores_kernel(ScoreParams p) {
   const float* Tb = p.T + (long)b * SL * D;
   const float* Ub = p.Gu + (long)b * SL * D;
 
-  for (int e = tid; e < 64 * D; e += 256) {
-    const int j = e / D, c = e % D;
-    Ts[c * LDT + j] = (j0 + j < SL) ? Tb[(long)(j0 + j) * D + c] : 0.f;
-  }
+  stage_tile_f32(Tb, j0, SL, Ts, tid);
   float rbest[16]; int ridx[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { rbest[r] = -INFINITY; ridx[r] = 0x7fffffff; }
+  __syncthreads();
+  float4 ta[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) ta[q] = *reinterpret_cast<const float4*>(Ts + (wi * 32 + l31) * LDR + 64 * kh + 4 * q);
 
   const int ntile = (SL + 63) / 64;
-  for (int ut = 0; ut < ntile; ++ut) {
+  const int tper = (ntile + p.ksplit - 1) / p.ksplit;
+  const int ut_end = min(ntile, ((int)blockIdx.z + 1) * tper);
+  for (int ut = blockIdx.z * tper; ut < ut_end; ++ut) {
     const int k0 = ut * 64;
     __syncthreads();
-    for (int e = tid; e < 64 * D; e += 256) {
-      const int k = e / D, c = e % D;
-      Us[c * LDT + k] = (k0 + k < SL) ? Ub[(long)(k0 + k) * D + c] : 0.f;
-    }
+    stage_tile_f32(Ub, k0, SL, Us, tid);
     __syncthreads();
-    f32x16 acc;
+    float4 ub[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-    for (int kk = 0; kk < D / 2; ++kk) {
-      const int c = 2 * kk + kh;
-      acc = mfma32(Ts[c * LDT + wi * 32 + l31], Us[c * LDT + wu * 32 + l31], acc);
+    for (int q = 0; q < 16; ++q) ub[q] = *reinterpret_cast<const float4*>(Us + (wu * 32 + l31) * LDR + 64 * kh + 4 * q);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc0 = mfma32(ta[q].x, ub[q].x, acc0);
+      acc1 = mfma32(ta[q].y, ub[q].y, acc1);
+      acc0 = mfma32(ta[q].z, ub[q].z, acc0);
+      acc1 = mfma32(ta[q].w, ub[q].w, acc1);
     }
     const int kcol = k0 + wu * 32 + l31;
     const bool kvalid = kcol < SL;
@@ -71,7 +100,7 @@ __global__ __launch_bounds__(256) void coattn_scores_kernel(ScoreParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = j0 + wi * 32 + mfma_row(r, lane);
-      const float a = tanhf(acc[r]);
+      const float a = tanhf(acc0[r] + acc1[r]);
       if (kvalid && j < SL) {
         better_first(rbest[r], ridx[r], a, kcol);
         better_first(cbest, cidx, a, j);
@@ -123,8 +152,9 @@ __global__ __launch_bounds__(256) void coattn_scores_kernel(ScoreParams p) {
       float v = rbest[r]; int i = ridx[r];
       better_first(v, i, xv[0][jr], xi[0][jr]);
       if (j0 + jr < SL) {
-        p.rowmax[(long)b * SL + j0 + jr] = v;
-        p.argrow[(long)b * SL + j0 + jr] = i;
+        const long o = ((long)b * p.ksplit + blockIdx.z) * SL + j0 + jr;
+        p.rowmax_part[o] = v;
+        p.argrow_part[o] = i;
       }
     }
   }
@@ -149,12 +179,21 @@ __global__ __launch_bounds__(256) void coattn_scores_bf16_kernel(ScoreParams p) 
   const float* Tb = p.T + (long)b * SL * D;
   const float* Ub = p.Gu + (long)b * SL * D;
   auto stage = [&](const float* src, int row0, __bf16* dst) {
-    for (int e = tid; e < 64 * (D / 4); e += 256) {
-      const int j = e / (D / 4), c4 = (e % (D / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + j < SL) v = *reinterpret_cast<const float4*>(src + (long)(row0 + j) * D + c4);
+    float4 v[8];                                        // every load in flight before the first use (clamped rows)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      const int j = e >> 5, c4 = (e & 31) * 4;
+      v[i] = *reinterpret_cast<const float4*>(src + (long)min(row0 + j, SL - 1) * D + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      const int j = e >> 5, c4 = (e & 31) * 4;
+      const bool ok = row0 + j < SL;
       bf16x4_t o;
-      o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+      o[0] = (__bf16)(ok ? v[i].x : 0.f); o[1] = (__bf16)(ok ? v[i].y : 0.f);
+      o[2] = (__bf16)(ok ? v[i].z : 0.f); o[3] = (__bf16)(ok ? v[i].w : 0.f);
       *reinterpret_cast<bf16x4_t*>(dst + j * LDB + c4) = o;
     }
   };
@@ -163,7 +202,9 @@ __global__ __launch_bounds__(256) void coattn_scores_bf16_kernel(ScoreParams p) 
 #pragma unroll
   for (int r = 0; r < 16; ++r) { rbest[r] = -INFINITY; ridx[r] = 0x7fffffff; }
   const int ntile = (SL + 63) / 64;
-  for (int ut = 0; ut < ntile; ++ut) {
+  const int tper = (ntile + p.ksplit - 1) / p.ksplit;
+  const int ut_end = min(ntile, ((int)blockIdx.z + 1) * tper);
+  for (int ut = blockIdx.z * tper; ut < ut_end; ++ut) {
     const int k0 = ut * 64;
     __syncthreads();
     stage(Ub, k0, Us);
@@ -232,8 +273,9 @@ __global__ __launch_bounds__(256) void coattn_scores_bf16_kernel(ScoreParams p) 
       float v = rbest[r]; int i = ridx[r];
       better_first(v, i, xv[0][jr], xi[0][jr]);
       if (j0 + jr < SL) {
-        p.rowmax[(long)b * SL + j0 + jr] = v;
-        p.argrow[(long)b * SL + j0 + jr] = i;
+        const long o = ((long)b * p.ksplit + blockIdx.z) * SL + j0 + jr;
+        p.rowmax_part[o] = v;
+        p.argrow_part[o] = i;
       }
     }
   }
@@ -261,7 +303,8 @@ __device__ float block_max(float v, float* red) {
 struct FinishParams {
   const float* Gu; const float* Gi;
   const float* colmax_part; const int* argcol_part; int nblk;
-  const float* rowmax;
+  const float* rowmax_part; const int* argrow_part; int ksplit;
+  float* rowmax; int* argrow;
   float* colmax; int* argcol;
   float* soft_u; float* soft_i;
   float* atte_u; long ld_u;  // atte_u[b*ld_u + c]
@@ -269,14 +312,15 @@ struct FinishParams {
   int SL;
 };
 
-__global__ __launch_bounds__(256) void coattn_finish_kernel(FinishParams p) {
+// 1024 threads per sample: the weighted sums over the SL positions run as 8 chains of SL/8 terms per column
+__global__ __launch_bounds__(1024) void coattn_finish_kernel(FinishParams p) {
   extern __shared__ float sm[];  // su[SL], si[SL]
-  __shared__ float red[4];
-  __shared__ float part[2][D];
+  __shared__ float red[16];
+  __shared__ float part[8][D];
   const int tid = threadIdx.x, b = blockIdx.x, SL = p.SL;
   float* su = sm; float* si = sm + SL;
   float mu = -INFINITY, mi = -INFINITY;
-  for (int k = tid; k < SL; k += 256) {
+  for (int k = tid; k < SL; k += 1024) {
     float v = -INFINITY; int idx = 0x7fffffff;
     for (int q = 0; q < p.nblk; ++q) {
       const long o = ((long)b * p.nblk + q) * SL + k;
@@ -284,34 +328,39 @@ __global__ __launch_bounds__(256) void coattn_finish_kernel(FinishParams p) {
     }
     p.colmax[(long)b * SL + k] = v; p.argcol[(long)b * SL + k] = idx;
     su[k] = v; mu = fmaxf(mu, v);
-    const float rv = p.rowmax[(long)b * SL + k];
+    float rv = -INFINITY; int ridx = 0x7fffffff;
+    for (int q = 0; q < p.ksplit; ++q) {   // ascending column ranges: ties keep the first column
+      const long o = ((long)b * p.ksplit + q) * SL + k;
+      better_first(rv, ridx, p.rowmax_part[o], p.argrow_part[o]);
+    }
+    p.rowmax[(long)b * SL + k] = rv; p.argrow[(long)b * SL + k] = ridx;
     si[k] = rv; mi = fmaxf(mi, rv);
   }
   mu = block_max(mu, red);
   mi = block_max(mi, red);
   float zu = 0.f, zi = 0.f;
-  for (int k = tid; k < SL; k += 256) {
+  for (int k = tid; k < SL; k += 1024) {
     const float eu = expf(su[k] - mu), ei = expf(si[k] - mi);
     su[k] = eu; si[k] = ei; zu += eu; zi += ei;
   }
   zu = block_sum(zu, red);
   zi = block_sum(zi, red);
-  for (int k = tid; k < SL; k += 256) {
+  for (int k = tid; k < SL; k += 1024) {
     su[k] /= zu; si[k] /= zi;
     p.soft_u[(long)b * SL + k] = su[k];
     p.soft_i[(long)b * SL + k] = si[k];
   }
   __syncthreads();
-  const int c = tid & 127, half = tid >> 7;
+  const int c = tid & 127, grp = tid >> 7;
   for (int which = 0; which < 2; ++which) {
     const float* G = (which == 0 ? p.Gu : p.Gi) + (long)b * SL * D;
     const float* s = which == 0 ? su : si;
     float a = 0.f;
-    for (int k = half; k < SL; k += 2) a += s[k] * G[(long)k * D + c];
-    part[half][c] = a;
+    for (int k = grp; k < SL; k += 8) a += s[k] * G[(long)k * D + c];
+    part[grp][c] = a;
     __syncthreads();
-    if (half == 0) {
-      const float v = part[0][c] + part[1][c];
+    if (grp == 0) {
+      const float v = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
       if (which == 0) p.atte_u[(long)b * p.ld_u + c] = v; else p.atte_i[(long)b * p.ld_i + c] = v;
     }
     __syncthreads();
@@ -328,14 +377,14 @@ struct BwdPrepParams {
   int SL;
 };
 
-__global__ __launch_bounds__(256) void coattn_bwd_prep_kernel(BwdPrepParams p) {
+__global__ __launch_bounds__(1024) void coattn_bwd_prep_kernel(BwdPrepParams p) {
   extern __shared__ float sm[];  // ds_u[SL], ds_i[SL]
-  __shared__ float red[4];
+  __shared__ float red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, SL = p.SL;
   float* dsu = sm; float* dsi = sm + SL;
   const float dau0 = p.d_atte_u[(long)b * p.ld_du + lane], dau1 = p.d_atte_u[(long)b * p.ld_du + 64 + lane];
   const float dai0 = p.d_atte_i[(long)b * p.ld_di + lane], dai1 = p.d_atte_i[(long)b * p.ld_di + 64 + lane];
-  for (int k = wave; k < SL; k += 4) {
+  for (int k = wave; k < SL; k += 16) {
     const float* gu = p.Gu + ((long)b * SL + k) * D;
     const float* gi = p.Gi + ((long)b * SL + k) * D;
     float su = gu[lane] * dau0 + gu[64 + lane] * dau1;
@@ -348,13 +397,13 @@ __global__ __launch_bounds__(256) void coattn_bwd_prep_kernel(BwdPrepParams p) {
   }
   __syncthreads();
   float du = 0.f, di = 0.f;
-  for (int k = tid; k < SL; k += 256) {
+  for (int k = tid; k < SL; k += 1024) {
     du += p.soft_u[(long)b * SL + k] * dsu[k];
     di += p.soft_i[(long)b * SL + k] * dsi[k];
   }
   du = block_sum(du, red);
   di = block_sum(di, red);
-  for (int k = tid; k < SL; k += 256) {
+  for (int k = tid; k < SL; k += 1024) {
     const long o = (long)b * SL + k;
     const float cm = p.colmax[o], rm = p.rowmax[o];
     p.dSc[o] = p.soft_u[o] * (dsu[k] - du) * (1.f - cm * cm);
@@ -445,7 +494,7 @@ __global__ __launch_bounds__(256) void coattn_bwd_rows_kernel(BwdRowsParams p) {
 // workspace floats needed by forward: T [B*SL*128] + colmax_part [B*nblk*SL] + argcol_part (int) [B*nblk*SL]
 size_t umpr_coattn_fwd_ws_bytes(int B, int SL) {
   const int nblk = cdiv(SL, 64);
-  return ((size_t)B * nblk * SL * 2) * sizeof(float);
+  return ((size_t)B * nblk * SL * 4) * sizeof(float);
 }
 
 int umpr_coattn_fwd_impl(const float* Gu, const float* Gi, const float* M, int B, int SL, float* T, float* soft_u,
@@ -457,14 +506,18 @@ int umpr_coattn_fwd_impl(const float* Gu, const float* Gi, const float* M, int B
   UmprGemm g;
   g.A = Gi; g.lda = D; g.B = M; g.ldb = D; g.C = T; g.ldc = D; g.M = B * SL; g.N = D; g.K = D;
   if (int rc = umpr_gemm(g, s)) return rc;
+  // one 64 x 64 score tile per workgroup: nblk^2 * B workgroups instead of nblk * B serial tile loops
+  const int ksplit = nblk;
   float* cpart = ws;
   int* apart = reinterpret_cast<int*>(ws + (size_t)B * nblk * SL);
-  ScoreParams sp{T, Gu, rowmax, argrow, cpart, apart, SL, nblk};
-  if (bf16_scores) coattn_scores_bf16_kernel<<<dim3(nblk, B), 256, 0, s>>>(sp);
-  else coattn_scores_kernel<<<dim3(nblk, B), 256, 0, s>>>(sp);
+  float* rpart = ws + (size_t)2 * B * nblk * SL;
+  int* arpart = reinterpret_cast<int*>(ws + (size_t)3 * B * nblk * SL);
+  ScoreParams sp{T, Gu, rpart, arpart, cpart, apart, SL, nblk, ksplit};
+  if (bf16_scores) coattn_scores_bf16_kernel<<<dim3(nblk, B, ksplit), 256, 0, s>>>(sp);
+  else coattn_scores_kernel<<<dim3(nblk, B, ksplit), 256, 0, s>>>(sp);
   UMPR_LAUNCH_CHECK("coattn_scores");
-  FinishParams fp{Gu, Gi, cpart, apart, nblk, rowmax, colmax, argcol, soft_u, soft_i, atte_u, ld_u, atte_i, ld_i, SL};
-  coattn_finish_kernel<<<B, 256, 2 * SL * sizeof(float), s>>>(fp);
+  FinishParams fp{Gu, Gi, cpart, apart, nblk, rpart, arpart, ksplit, rowmax, argrow, colmax, argcol, soft_u, soft_i, atte_u, ld_u, atte_i, ld_i, SL};
+  coattn_finish_kernel<<<B, 1024, 2 * SL * sizeof(float), s>>>(fp);
   UMPR_LAUNCH_CHECK("coattn_finish");
   return 0;
 }
@@ -483,7 +536,7 @@ int umpr_coattn_bwd_impl(const float* Gu, const float* Gi, const float* M, const
   float* dSc = ws; float* dSr = ws + (size_t)B * SL; float* dT = dSr + (size_t)B * SL;
   float* slab = dT + (size_t)B * SL * D;
   BwdPrepParams pp{Gu, Gi, d_atte_u, ld_du, d_atte_i, ld_di, d_soft_u, d_soft_i, soft_u, soft_i, colmax, rowmax, dSc, dSr, SL};
-  coattn_bwd_prep_kernel<<<B, 256, 2 * SL * sizeof(float), s>>>(pp);
+  coattn_bwd_prep_kernel<<<B, 1024, 2 * SL * sizeof(float), s>>>(pp);
   UMPR_LAUNCH_CHECK("coattn_bwd_prep");
   BwdRowsParams rp{Gu, T, soft_u, soft_i, d_atte_u, ld_du, d_atte_i, ld_di, dSc, dSr, argcol, argrow, dGu, dT, dGi, SL, accumulate};
   coattn_bwd_rows_kernel<<<dim3(cdiv(SL, 16), B), 256, 4 * SL * sizeof(float), s>>>(rp);

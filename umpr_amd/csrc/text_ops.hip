@@ -31,42 +31,53 @@ struct SnetFwdParams {
   int S, L;
 };
 
-__global__ __launch_bounds__(256) void snet_pool_fwd_kernel(SnetFwdParams p) {
-  __shared__ float part[4][D];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+// one wave per sentence (B*S waves over the grid); the per-sample sum over sentences is snet_senti_kernel
+__global__ __launch_bounds__(256) void snet_pool_fwd_kernel(SnetFwdParams p, long nsent) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long sent = (long)blockIdx.x * 4 + wave;
+  if (sent >= nsent) return;
   const float w = p.Ws[lane];
-  float s0 = 0.f, s1 = 0.f;
-  for (int s = wave; s < p.S; s += 4) {
-    const long sent = (long)b * p.S + s;
-    const float* X = p.X + sent * p.L * D;
-    const float* U = p.U + sent * p.L * AT;
-    float e = -INFINITY;  // lane l holds e[l]
-    for (int l = 0; l < p.L; ++l) {
-      const float v = wave_sum(w * U[l * AT + lane]);
-      if (lane == l) e = v;
-    }
-    const float m = wave_max(e);
-    const float ex = lane < p.L ? expf(e - m) : 0.f;
-    const float z = wave_sum(ex);
-    const float pr = ex / z;
-    if (lane < p.L) p.P[sent * p.L + lane] = pr;
-    float a0 = 0.f, a1 = 0.f;
-    for (int l = 0; l < p.L; ++l) {
-      const float pl = __shfl(pr, l, 64);
-      a0 += pl * X[l * D + lane];
-      a1 += pl * X[l * D + 64 + lane];
-    }
-    p.self_atte[sent * D + lane] = a0;
-    p.self_atte[sent * D + 64 + lane] = a1;
-    float ws = 0.f;
-    for (int i = lane; i < p.wl; i += 64) ws += p.word_soft[sent * p.wl + i];
-    ws = wave_sum(ws);
-    if (lane == 0) p.wsum[sent] = ws;
-    s0 += ws * a0; s1 += ws * a1;
+  const float* X = p.X + sent * p.L * D;
+  const float* U = p.U + sent * p.L * AT;
+  float e = -INFINITY;  // lane l holds e[l]
+  int l = 0;
+  for (; l + 3 < p.L; l += 4) {   // four independent reductions in flight
+    const float v0 = wave_sum(w * U[l * AT + lane]);
+    const float v1 = wave_sum(w * U[(l + 1) * AT + lane]);
+    const float v2 = wave_sum(w * U[(l + 2) * AT + lane]);
+    const float v3 = wave_sum(w * U[(l + 3) * AT + lane]);
+    e = lane == l ? v0 : lane == l + 1 ? v1 : lane == l + 2 ? v2 : lane == l + 3 ? v3 : e;
   }
-  part[wave][lane] = s0; part[wave][64 + lane] = s1;
-  __syncthreads();
-  if (tid < D) p.senti[(long)b * p.ld_senti + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  for (; l < p.L; ++l) {
+    const float v = wave_sum(w * U[l * AT + lane]);
+    if (lane == l) e = v;
+  }
+  const float m = wave_max(e);
+  const float ex = lane < p.L ? expf(e - m) : 0.f;
+  const float z = wave_sum(ex);
+  const float pr = ex / z;
+  if (lane < p.L) p.P[sent * p.L + lane] = pr;
+  float a0 = 0.f, a1 = 0.f;
+  for (l = 0; l < p.L; ++l) {
+    const float pl = __shfl(pr, l, 64);
+    a0 += pl * X[l * D + lane];
+    a1 += pl * X[l * D + 64 + lane];
+  }
+  p.self_atte[sent * D + lane] = a0;
+  p.self_atte[sent * D + 64 + lane] = a1;
+  float ws = 0.f;
+  for (int i = lane; i < p.wl; i += 64) ws += p.word_soft[sent * p.wl + i];
+  ws = wave_sum(ws);
+  if (lane == 0) p.wsum[sent] = ws;
+}
+
+// senti[b] = sum_s wsum[b][s] * self_atte[b][s]   (fixed order)
+__global__ __launch_bounds__(128) void snet_senti_kernel(const float* __restrict__ wsum, const float* __restrict__ self_atte,
+                                                         float* __restrict__ senti, long ld_senti, int S) {
+  const int b = blockIdx.x, d = threadIdx.x;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += wsum[(long)b * S + s] * self_atte[((long)b * S + s) * D + d];
+  senti[(long)b * ld_senti + d] = v;
 }
 
 struct SnetBwdParams {
@@ -80,14 +91,16 @@ struct SnetBwdParams {
   int S, L;
 };
 
-__global__ __launch_bounds__(256) void snet_pool_bwd_kernel(SnetBwdParams p) {
+// one wave per sentence; dWs_part[workgroup][64] = the four waves' partial sums in wave order
+__global__ __launch_bounds__(256) void snet_pool_bwd_kernel(SnetBwdParams p, long nsent) {
   __shared__ float part[4][AT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-  const float w = p.Ws[lane];
-  const float ds0 = p.d_senti[(long)b * p.ld_ds + lane], ds1 = p.d_senti[(long)b * p.ld_ds + 64 + lane];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long sent = (long)blockIdx.x * 4 + wave;
   float dws = 0.f;
-  for (int s = wave; s < p.S; s += 4) {
-    const long sent = (long)b * p.S + s;
+  if (sent < nsent) {
+    const long b = sent / p.S;
+    const float w = p.Ws[lane];
+    const float ds0 = p.d_senti[b * p.ld_ds + lane], ds1 = p.d_senti[b * p.ld_ds + 64 + lane];
     const float* X = p.X + sent * p.L * D;
     const float* U = p.U + sent * p.L * AT;
     const float ws = p.wsum[sent];
@@ -98,13 +111,21 @@ __global__ __launch_bounds__(256) void snet_pool_bwd_kernel(SnetBwdParams p) {
       for (int i = lane; i < p.wl; i += 64) p.d_word_soft[sent * p.wl + i] = dwsum;
     const float pr = lane < p.L ? p.P[sent * p.L + lane] : 0.f;
     float dp = 0.f;  // lane l holds dp[l]
-    for (int l = 0; l < p.L; ++l) {
+    int l = 0;
+    for (; l + 3 < p.L; l += 4) {   // four independent reductions in flight
+      const float v0 = wave_sum(X[l * D + lane] * g0 + X[l * D + 64 + lane] * g1);
+      const float v1 = wave_sum(X[(l + 1) * D + lane] * g0 + X[(l + 1) * D + 64 + lane] * g1);
+      const float v2 = wave_sum(X[(l + 2) * D + lane] * g0 + X[(l + 2) * D + 64 + lane] * g1);
+      const float v3 = wave_sum(X[(l + 3) * D + lane] * g0 + X[(l + 3) * D + 64 + lane] * g1);
+      dp = lane == l ? v0 : lane == l + 1 ? v1 : lane == l + 2 ? v2 : lane == l + 3 ? v3 : dp;
+    }
+    for (; l < p.L; ++l) {
       const float v = wave_sum(X[l * D + lane] * g0 + X[l * D + 64 + lane] * g1);
       if (lane == l) dp = v;
     }
     const float dot = wave_sum(pr * dp);
     const float de = pr * (dp - dot);
-    for (int l = 0; l < p.L; ++l) {
+    for (l = 0; l < p.L; ++l) {
       const float pl = __shfl(pr, l, 64), del = __shfl(de, l, 64);
       float* dx = p.dX + (sent * p.L + l) * D;
       dx[lane] = pl * g0; dx[64 + lane] = pl * g1;
@@ -115,7 +136,7 @@ __global__ __launch_bounds__(256) void snet_pool_bwd_kernel(SnetBwdParams p) {
   }
   part[wave][lane] = dws;
   __syncthreads();
-  if (tid < AT) p.dWs_part[(long)b * AT + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  if (tid < AT) p.dWs_part[(long)blockIdx.x * AT + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
 // -------------------------------------------------------------------------------------------------- C-Net
@@ -556,16 +577,18 @@ __global__ void colsum_stage1_kernel(const float* __restrict__ src, long rows, i
 }
 __global__ void colsum_stage2_kernel(const float* __restrict__ part, int chunks, int cols, float* __restrict__ dst,
                                      int accumulate) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  __shared__ float red[16][64];                         // blockDim.x = 64 * groups, groups <= 16
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6, ngrp = blockDim.x >> 6;
   const int j = blockIdx.x * 64 + c;
   float v = 0.f;
   if (j < cols)
-    for (int q = grp; q < chunks; q += 4) v += part[(long)q * cols + j];
+    for (int q = grp; q < chunks; q += ngrp) v += part[(long)q * cols + j];
   red[grp][c] = v;
   __syncthreads();
   if (grp == 0 && j < cols) {
-    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    float t;
+    if (ngrp == 4) t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    else { t = 0.f; for (int g = 0; g < ngrp; ++g) t += red[g][c]; }
     dst[j] = accumulate ? dst[j] + t : t;
   }
 }
@@ -690,13 +713,16 @@ int umpr_snet_fwd_impl(const float* X, const float* Ms, const float* Ws, const f
   g.act = UMPR_ACT_TANH;
   if (int rc = umpr_gemm(g, s)) return rc;
   SnetFwdParams p{X, U, Ws, word_soft, wl, P, wsum, self_atte, senti, ld_senti, S, L};
-  snet_pool_fwd_kernel<<<B, 256, 0, s>>>(p);
+  const long nsent = (long)B * S;
+  snet_pool_fwd_kernel<<<(unsigned)((nsent + 3) / 4), 256, 0, s>>>(p, nsent);
   UMPR_LAUNCH_CHECK("snet_pool_fwd");
+  snet_senti_kernel<<<B, D, 0, s>>>(wsum, self_atte, senti, ld_senti, S);
+  UMPR_LAUNCH_CHECK("snet_senti");
   return 0;
 }
 
 size_t umpr_snet_bwd_ws_bytes_impl(int B, int S, int L) {
-  return ((size_t)B * S * L * AT + (size_t)B * AT + (size_t)512 * AT * D) * sizeof(float);
+  return ((size_t)B * S * L * AT + ((size_t)B * S + 3) / 4 * AT + (size_t)512 * AT * D) * sizeof(float);
 }
 
 int umpr_snet_bwd_impl(const float* X, const float* Ms, const float* Ws, const float* U, const float* P,
@@ -704,9 +730,11 @@ int umpr_snet_bwd_impl(const float* X, const float* Ms, const float* Ws, const f
                        const float* d_self_atte, int B, int S, int L, int wl, float* dX, float* dMs, float* dWs,
                        float* d_word_soft, float* ws, size_t ws_bytes, hipStream_t s) {
   UMPR_REQUIRE(ws_bytes >= umpr_snet_bwd_ws_bytes_impl(B, S, L), "snet_bwd: workspace too small");
-  float* dPre = ws; float* dWs_part = ws + (size_t)B * S * L * AT; float* slab = dWs_part + (size_t)B * AT;
+  const long nsent = (long)B * S;
+  const int nwg = (int)((nsent + 3) / 4);
+  float* dPre = ws; float* dWs_part = ws + (size_t)B * S * L * AT; float* slab = dWs_part + (size_t)nwg * AT;
   SnetBwdParams p{X, U, Ws, P, wsum, self_atte, d_senti, ld_ds, d_self_atte, dX, dPre, dWs_part, d_word_soft, wl, S, L};
-  snet_pool_bwd_kernel<<<B, 256, 0, s>>>(p);
+  snet_pool_bwd_kernel<<<nwg, 256, 0, s>>>(p, nsent);
   UMPR_LAUNCH_CHECK("snet_pool_bwd");
   const int R = B * S * L;
   UmprGemm g;  // dX += dPre Ms
@@ -716,7 +744,7 @@ int umpr_snet_bwd_impl(const float* X, const float* Ms, const float* Ws, const f
   h.A = dPre; h.lda = AT; h.transA = true; h.B = X; h.ldb = D; h.C = dMs; h.ldc = D; h.M = AT; h.N = D; h.K = R;
   h.split_k = 0; h.ws = slab; h.ws_bytes = (size_t)512 * AT * D * sizeof(float);
   if (int rc = umpr_gemm(h, s)) return rc;
-  colsum_stage2_kernel<<<1, 256, 0, s>>>(dWs_part, B, AT, dWs, 0);
+  colsum_stage2_kernel<<<1, 1024, 0, s>>>(dWs_part, nwg, AT, dWs, 0);
   UMPR_LAUNCH_CHECK("snet_dWs");
   return 0;
 }
