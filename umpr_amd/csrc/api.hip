@@ -19,6 +19,8 @@ void umpr_set_error(const char* fmt, ...) {
 
 // ---- profiling registry -------------------------------------------------------------------------------------
 namespace {
+// UMPR_FC_SMALL=0: batch-sized-M products stay on the tiled GEMM (A/B runs)
+const bool g_fc_small = [] { const char* v = getenv("UMPR_FC_SMALL"); return !(v && v[0] == '0'); }();
 struct ProfRec { hipEvent_t e0, e1; int family; double work; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -238,6 +240,12 @@ int umpr_snet_bwd(const float* X, const float* Ms, const float* Ws, const float*
 // ------------------------------------------------------------------------------------------------ merge
 int umpr_review_merge_fwd(const float* repr_u, const float* repr_i, const float* W_u, const float* W_i, int B,
                           float* out, void* stream) {
+  if (g_fc_small && umpr_fc_small_ok(B, D, 2 * D)) {
+    // batch-sized M: the register-streaming kernels (no LDS stage, no barrier per k-tile) instead of one workgroup of
+    // the tiled GEMM walking 16 k-tiles one global round trip at a time (35 us -> 4 us at B = 32)
+    if (int rc = umpr_fc_small_fwd(repr_u, W_u, nullptr, out, B, D, 2 * D, UMPR_ACT_NONE, nullptr, 0, S(stream))) return rc;
+    return umpr_fc_small_fwd(repr_i, W_i, nullptr, out, B, D, 2 * D, UMPR_ACT_TANH, nullptr, 0, S(stream), 1);
+  }
   UmprGemm g;
   g.A = repr_u; g.lda = 2 * D; g.B = W_u; g.ldb = 2 * D; g.transB = true; g.C = out; g.ldc = D; g.M = B; g.N = D; g.K = 2 * D;
   if (int rc = umpr_gemm(g, S(stream))) return rc;
@@ -255,6 +263,13 @@ int umpr_review_merge_bwd(const float* repr_u, const float* repr_i, const float*
   const float* Wm[2] = {W_u, W_i};
   float* drepr[2] = {d_repr_u, d_repr_i};
   float* dW[2] = {dW_u, dW_i};
+  if (g_fc_small && umpr_fc_small_ok(B, D, 2 * D)) {
+    for (int q = 0; q < 2; ++q) {
+      if (int rc = umpr_fc_small_dx(dpre, Wm[q], drepr[q], B, D, 2 * D, nullptr, 0, S(stream))) return rc;
+      if (int rc = umpr_fc_small_dw(dpre, reprs[q], dW[q], B, D, 2 * D, S(stream))) return rc;
+    }
+    return 0;
+  }
   for (int q = 0; q < 2; ++q) {
     UmprGemm g;  // d_repr = dpre W
     g.A = dpre; g.lda = D; g.B = Wm[q]; g.ldb = 2 * D; g.C = drepr[q]; g.ldc = 2 * D; g.M = B; g.N = 2 * D; g.K = D;
@@ -388,7 +403,6 @@ int umpr_vgg16_features_fwd(const float* images, const float* const* params, int
 }
 
 namespace {
-const bool g_fc_small = [] { const char* v = getenv("UMPR_FC_SMALL"); return !(v && v[0] == '0'); }();
 // classifier activations: pool5 input [n][25088], ReLU outputs of fc1 / fc2 and their dropout outputs ([n][4096] each)
 struct ClsActs { const float* pool5; float* fc[2]; float* drop[2]; };
 

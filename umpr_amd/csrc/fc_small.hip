@@ -27,6 +27,7 @@ struct FcParams {
   int M, N, K;       // batch rows, output features, input features
   int split, per;    // reduction slices and their length (multiple of 8)
   int act;
+  int accumulate;    // fwd, split == 1: out = act(out + x W^T + bias)
 };
 
 // out[m][n] over a K-slice.  TM row tiles of 32 batch rows.  Workgroup = 4 waves = 4 column groups of 32.
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcParams p) {
           float v = acc[i][r];
           if (p.split == 1) {
             if (p.bias) v += p.bias[n];
+            if (p.accumulate) v += p.out[(long)m * p.N + n];
             v = apply_act(v, p.act);
           }
           p.out[((long)split * p.M + m) * p.N + n] = v;
@@ -223,12 +225,12 @@ size_t umpr_fc_small_ws_bytes(int M, int N, int K) {
 
 // out [M][N] = act(x [M][K] W[N][K]^T + bias)
 int umpr_fc_small_fwd(const float* x, const float* W, const float* bias, float* out, int M, int N, int K, int act,
-                      float* ws, size_t ws_bytes, hipStream_t s) {
+                      float* ws, size_t ws_bytes, hipStream_t s, int accumulate) {
   UMPR_REQUIRE(umpr_fc_small_ok(M, N, K), "fc_small_fwd: unsupported shape %d x %d x %d", M, N, K);
   const int strips = cdiv(N, 32);
-  int split = pick_split(strips, K, 4096);
+  int split = accumulate ? 1 : pick_split(strips, K, 4096);
   while (split > 1 && (size_t)split * M * N * sizeof(float) > ws_bytes) --split;
-  FcParams p{x, W, split > 1 ? ws : out, bias, M, N, K, split, cdiv(cdiv(K, split), 8) * 8, act};
+  FcParams p{x, W, split > 1 ? ws : out, bias, M, N, K, split, cdiv(cdiv(K, split), 8) * 8, act, accumulate};
   p.split = cdiv(K, p.per);
   if (p.split == 1) p.out = out;
   dim3 grid(cdiv(strips, 4), p.split);

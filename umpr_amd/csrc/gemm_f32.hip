@@ -192,8 +192,13 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   // float4 staging needs 16-B aligned rows and a contiguous extent that is a multiple of 4 (no partial vectors)
   p.vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && (((g.transA ? g.M : g.K) & 3) == 0);
   p.vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && (((g.transB ? g.K : g.N) & 3) == 0);
-  const int BM = g.M <= 64 ? 64 : 128;
-  const int BN = g.N <= 64 ? 64 : 128;
+  int BM = g.M <= 64 ? 64 : 128;
+  int BN = g.N <= 64 ? 64 : 128;
+  // a grid that leaves CUs idle (the text path's [12800 x 128] x 128 products: 100 tiles of 128 x 128) takes smaller
+  // tiles: each halving doubles the workgroups in flight
+  static const int small_grid = [] { const char* v = getenv("UMPR_GEMM_SMALL_GRID"); return v ? atoi(v) : 384; }();
+  if ((long)cdiv(g.M, BM) * cdiv(g.N, BN) < small_grid && BM == 128) BM = 64;
+  if ((long)cdiv(g.M, BM) * cdiv(g.N, BN) < small_grid && BN == 128) BN = 64;
   const int tm = cdiv(g.M, BM), tn = cdiv(g.N, BN);
   int split = g.split_k;
   if (split <= 0) {  // auto: aim for >= 512 workgroups when K is deep enough to share
