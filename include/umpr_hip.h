@@ -228,6 +228,14 @@ int umpr_vgg16_classifier_fwd_compact(const float* const* params, int n_img, int
 int umpr_vgg16_classifier_bwd_compact(const float* const* params, int n_img, int train, const float* cls_arena,
                                       const uint8_t* masks, const float* d_out, float* const* grads, float* d_pool5,
                                       float* ws, size_t ws_bytes, void* stream);
+/* The same under mixed precision (torch.autocast would run these nn.Linear layers in bf16 too): operands rounded to
+ * bf16 in registers, v_mfma_f32_32x32x16_bf16 with fp32 accumulation; everything in memory stays fp32. */
+int umpr_vgg16_classifier_fwd_compact_bf16(const float* const* params, int n_img, int train, int use_masks,
+                                           uint64_t seed, float* cls_arena, uint8_t* masks, float* out, float* ws,
+                                           size_t ws_bytes, void* stream);
+int umpr_vgg16_classifier_bwd_compact_bf16(const float* const* params, int n_img, int train, const float* cls_arena,
+                                           const uint8_t* masks, const float* d_out, float* const* grads,
+                                           float* d_pool5, float* ws, size_t ws_bytes, void* stream);
 
 /* ---- K11-K12: visual head + fusion + losses (model.py:218-228,267-277) ----------------------------------------
  * V = 0 selects the review_net_only branch (model.py:267-269).  loss [3] = (loss, loss_r, loss_v). */

@@ -82,6 +82,8 @@ SIGNATURES = {
     "umpr_vgg16_cls_arena_bytes": ("i", "z"),
     "umpr_vgg16_classifier_fwd_compact": ("piiiuppppzp", "i"),
     "umpr_vgg16_classifier_bwd_compact": ("piippppppzp", "i"),
+    "umpr_vgg16_classifier_fwd_compact_bf16": ("piiiuppppzp", "i"),
+    "umpr_vgg16_classifier_bwd_compact_bf16": ("piippppppzp", "i"),
     "umpr_head_fwd": ("pppppppppppppfiiipppppppp", "i"),
     "umpr_head_bwd": ("pppppppppppfiiippppppppppppppppppppp", "i"),
     "umpr_bce_head_fwd": ("plpppiipppzp", "i"),

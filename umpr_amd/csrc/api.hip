@@ -407,7 +407,7 @@ namespace {
 struct ClsActs { const float* pool5; float* fc[2]; float* drop[2]; };
 
 int classifier_fwd_impl(const float* const* params, int n, int train, int use_masks, uint64_t seed, const ClsActs& A,
-                        uint8_t* masks, float* out, float* ws, size_t ws_bytes, hipStream_t s) {
+                        uint8_t* masks, float* out, float* ws, size_t ws_bytes, hipStream_t s, int bf16 = 0) {
   // AdaptiveAvgPool2d(7) is the identity on the 7x7 map a 224x224 image produces
   const float* x = A.pool5;
   for (int j = 0; j < 3; ++j) {
@@ -416,7 +416,7 @@ int classifier_fwd_impl(const float* const* params, int n, int train, int use_ma
     if (g_fc_small && umpr_fc_small_ok(n, kFc[j][1], kFc[j][0])) {
       // batch-sized M: register-streaming kernels (fc_small.hip) instead of the LDS-tiled GEMM
       if (int rc = umpr_fc_small_fwd(x, params[26 + 2 * j], params[27 + 2 * j], y, n, kFc[j][1], kFc[j][0], act, ws,
-                                     ws_bytes, s)) return rc;
+                                     ws_bytes, s, 0, bf16)) return rc;
     } else {
       UmprGemm g;
       g.A = x; g.lda = kFc[j][0]; g.B = params[26 + 2 * j]; g.ldb = kFc[j][0]; g.transB = true;
@@ -478,7 +478,8 @@ size_t umpr_vgg16_classifier_bwd_ws_bytes(int n_img) {
 // classifier entries 26..31 are written).
 namespace {
 int classifier_bwd_impl(const float* const* params, int n, int train, const ClsActs& A, const uint8_t* masks,
-                        const float* d_out, float* const* grads, float* d_pool5, float* ws, size_t ws_bytes, hipStream_t s) {
+                        const float* d_out, float* const* grads, float* d_pool5, float* ws, size_t ws_bytes, hipStream_t s,
+                        int bf16 = 0) {
   float* gA = ws;
   float* gB = ws + (size_t)n * 4096;
   float* scratch = gB + (size_t)n * 4096;
@@ -496,7 +497,7 @@ int classifier_bwd_impl(const float* const* params, int n, int train, const ClsA
     }
     const bool small = g_fc_small && umpr_fc_small_ok(n, fout, fin);
     if (small) {  // dW[fout][fin] = g^T xin
-      if (int rc = umpr_fc_small_dw(g, xin, grads[26 + 2 * j], n, fout, fin, s)) return rc;
+      if (int rc = umpr_fc_small_dw(g, xin, grads[26 + 2 * j], n, fout, fin, s, bf16)) return rc;
     } else {
       UmprGemm w;
       w.A = g; w.lda = fout; w.transA = true; w.B = xin; w.ldb = fin; w.C = grads[26 + 2 * j]; w.ldc = fin;
@@ -506,7 +507,7 @@ int classifier_bwd_impl(const float* const* params, int n, int train, const ClsA
     if (int rc = umpr_colsum_rows(g, n, fout, fout, grads[27 + 2 * j], 0, s)) return rc;
     float* dxo = j == 0 ? d_pool5 : cur;
     if (small) {  // dx[n][fin] = g W
-      if (int rc = umpr_fc_small_dx(g, params[26 + 2 * j], dxo, n, fout, fin, scratch, slab_bytes, s)) return rc;
+      if (int rc = umpr_fc_small_dx(g, params[26 + 2 * j], dxo, n, fout, fin, scratch, slab_bytes, s, bf16)) return rc;
     } else {
       UmprGemm d;
       d.A = g; d.lda = fout; d.B = params[26 + 2 * j]; d.ldb = fin; d.C = dxo; d.ldc = fin; d.M = n;
@@ -533,6 +534,23 @@ int umpr_vgg16_classifier_bwd_compact(const float* const* params, int n, int tra
   UMPR_REQUIRE(ws_bytes >= umpr_vgg16_classifier_bwd_ws_bytes(n), "vgg16_classifier_bwd_compact: workspace too small");
   return classifier_bwd_impl(params, n, train, cls_acts_compact(const_cast<float*>(cls_arena), n), masks, d_out, grads,
                              d_pool5, ws, ws_bytes, S(stream));
+}
+
+// Mixed precision (BASELINE.json configs[4]): the three products of each layer take bf16-rounded operands on the bf16
+// matrix pipe with fp32 accumulation; weights, activations, biases, dropout and the gradients stay fp32 in memory.
+int umpr_vgg16_classifier_fwd_compact_bf16(const float* const* params, int n, int train, int use_masks, uint64_t seed,
+                                           float* cls_arena, uint8_t* masks, float* out, float* ws, size_t ws_bytes,
+                                           void* stream) {
+  UMPR_REQUIRE(n > 0 && params && cls_arena && out, "vgg16_classifier_fwd_compact_bf16: bad arguments");
+  return classifier_fwd_impl(params, n, train, use_masks, seed, cls_acts_compact(cls_arena, n), masks, out, ws, ws_bytes,
+                             S(stream), 1);
+}
+int umpr_vgg16_classifier_bwd_compact_bf16(const float* const* params, int n, int train, const float* cls_arena,
+                                           const uint8_t* masks, const float* d_out, float* const* grads, float* d_pool5,
+                                           float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(ws_bytes >= umpr_vgg16_classifier_bwd_ws_bytes(n), "vgg16_classifier_bwd_compact_bf16: workspace too small");
+  return classifier_bwd_impl(params, n, train, cls_acts_compact(const_cast<float*>(cls_arena), n), masks, d_out, grads,
+                             d_pool5, ws, ws_bytes, S(stream), 1);
 }
 
 size_t umpr_vgg16_features_bwd_ws_bytes(int n_img) {

@@ -188,6 +188,196 @@ __global__ __launch_bounds__(256) void fc_dw_kernel(FcParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same three products with bf16 operands on v_mfma_f32_32x32x16_bf16 (BASELINE.json configs[4]: mixed precision).
+// Operands stay fp32 in memory (master weights, fp32 activations) and are rounded to bf16 in registers on their way into
+// the MFMA; accumulation is fp32.  At 1/16 of the fp32 MFMA cycles the kernels are bound by the 411 MB weight stream
+// (fc1) instead of the matrix pipe.  Lane half h takes the eight reduction indices 16q + 8h .. 16q + 8h + 7.
+typedef __bf16 fc_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ fc_bf16x8 to_bf16x8(const float4& a, const float4& b) {
+  fc_bf16x8 r;
+  r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+  r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+  return r;
+}
+__device__ __forceinline__ f32x16 mfma_b16(fc_bf16x8 a, fc_bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// out[m][n] over a K-slice (K % 16 == 0).  A wave owns 64 output columns (two B tiles): x is re-read half as often.
+template <int TM>
+__global__ __launch_bounds__(256) void fc_fwd_b16_kernel(FcParams p) {
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const int nb = (blockIdx.x * 4 + wave) * 64;
+  if (nb >= p.N) return;
+  const int split = blockIdx.y;
+  const int k0 = split * p.per, k1 = min(p.K, k0 + p.per);
+  const float* wrow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nb + j * 32 + c;
+    wrow[j] = p.w + (long)(n < p.N ? n : p.N - 1) * p.K + 8 * h;   // columns past N compute garbage that is never stored
+  }
+  const float* xrow[TM];
+  bool mok[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = i * 32 + c;
+    mok[i] = m < p.M;
+    xrow[i] = p.x + (long)(mok[i] ? m : 0) * p.K + 8 * h;
+  }
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 2
+  for (int k = k0; k < k1; k += 16) {
+    fc_bf16x8 wv[2], xv[TM];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      wv[j] = to_bf16x8(*reinterpret_cast<const float4*>(wrow[j] + k), *reinterpret_cast<const float4*>(wrow[j] + k + 4));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float4 a = *reinterpret_cast<const float4*>(xrow[i] + k), b = *reinterpret_cast<const float4*>(xrow[i] + k + 4);
+      if (!mok[i]) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+      xv[i] = to_bf16x8(a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma_b16(xv[i], wv[j], acc[i][j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nb + j * 32 + c;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = i * 32 + mfma_row(r, lane);
+        if (m < p.M) {
+          float v = acc[i][j][r];
+          if (p.split == 1) {
+            if (p.bias) v += p.bias[n];
+            if (p.accumulate) v += p.out[(long)m * p.N + n];
+            v = apply_act(v, p.act);
+          }
+          p.out[((long)split * p.M + m) * p.N + n] = v;
+        }
+      }
+  }
+}
+
+// dx[m][k] over an N-slice (slices are multiples of 16; N itself only of 8: a half-empty last step is zero-filled)
+template <int TM>
+__global__ __launch_bounds__(256) void fc_dx_b16_kernel(FcParams p) {
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const int kcol = (blockIdx.x * 4 + wave) * 32 + c;       // this lane's output column (input feature)
+  const int split = blockIdx.y;
+  const int n0 = split * p.per, n1 = min(p.N, n0 + p.per);
+  const int kc = kcol < p.K ? kcol : p.K - 1;
+  const float* wcol = p.w + kc;
+  const float* grow[TM];
+  bool mok[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = i * 32 + c;
+    mok[i] = m < p.M;
+    grow[i] = p.x + (long)(mok[i] ? m : 0) * p.N;
+  }
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll 2
+  for (int n = n0; n < n1; n += 16) {
+    const bool nok = n + 8 * h < n1;                       // this lane half's eight n exist (n1 is a multiple of 8)
+    const int nn = nok ? n + 8 * h : n0;
+    float wf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[j] = wcol[(long)(nn + j) * p.K];
+    fc_bf16x8 wv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = (__bf16)(nok ? wf[j] : 0.f);
+    fc_bf16x8 gv[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float4 a = *reinterpret_cast<const float4*>(grow[i] + nn), b = *reinterpret_cast<const float4*>(grow[i] + nn + 4);
+      if (!mok[i] || !nok) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+      gv[i] = to_bf16x8(a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[i] = mfma_b16(gv[i], wv, acc[i]);
+  }
+  if (kcol < p.K) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = i * 32 + mfma_row(r, lane);
+        if (m < p.M) p.out[((long)split * p.M + m) * p.K + kcol] = acc[i][r];
+      }
+  }
+}
+
+// dW[n][k] = sum_m g[m][n] x[m][k]: wave tile 32 rows n x 128 columns k, batch rows in steps of 16
+__global__ __launch_bounds__(256) void fc_dw_b16_kernel(FcParams p) {
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const int n = blockIdx.y * 32 + c;                        // A row
+  const int kb = (blockIdx.x * 4 + wave) * 128;             // first output column of this wave
+  if (kb >= p.K) return;
+  const int nc = n < p.N ? n : p.N - 1;
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  int kc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int k = kb + j * 32 + c; kc[j] = k < p.K ? k : p.K - 1; }
+  for (int m0 = 0; m0 < p.M; m0 += 16) {
+    float af[8], bf[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = m0 + 8 * h + e;
+      const long mr = m < p.M ? m : 0;
+      af[e] = p.x[mr * p.N + nc];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j][e] = p.w[mr * p.K + kc[j]];
+    }
+    fc_bf16x8 a, b[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = m0 + 8 * h + e < p.M;
+      a[e] = (__bf16)(ok ? af[e] : 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j][e] = (__bf16)(ok ? bf[j][e] : 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = mfma_b16(a, b[j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = kb + j * 32 + c;
+    if (k < p.K) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nn = blockIdx.y * 32 + mfma_row(r, lane);
+        if (nn < p.N) p.out[(long)nn * p.K + k] = acc[j][r];
+      }
+    }
+  }
+}
+
 // out[m][c] = act(sum over slabs + bias): four interleaved chains in a fixed order
 __global__ void fc_reduce_kernel(const float* __restrict__ ws, int splits, long total, int cols, float* __restrict__ out,
                                  const float* __restrict__ bias, int act) {
@@ -225,8 +415,28 @@ size_t umpr_fc_small_ws_bytes(int M, int N, int K) {
 
 // out [M][N] = act(x [M][K] W[N][K]^T + bias)
 int umpr_fc_small_fwd(const float* x, const float* W, const float* bias, float* out, int M, int N, int K, int act,
-                      float* ws, size_t ws_bytes, hipStream_t s, int accumulate) {
+                      float* ws, size_t ws_bytes, hipStream_t s, int accumulate, int bf16) {
   UMPR_REQUIRE(umpr_fc_small_ok(M, N, K), "fc_small_fwd: unsupported shape %d x %d x %d", M, N, K);
+  if (bf16 && (K % 16) == 0) {
+    const int strips = cdiv(N, 64);
+    int split = accumulate ? 1 : pick_split(strips, K, 2048);
+    while (split > 1 && (size_t)split * M * N * sizeof(float) > ws_bytes) --split;
+    FcParams p{x, W, split > 1 ? ws : out, bias, M, N, K, split, cdiv(cdiv(K, split), 16) * 16, act, accumulate};
+    p.split = cdiv(K, p.per);
+    if (p.split == 1) p.out = out;
+    dim3 grid(cdiv(strips, 4), p.split);
+    UmprProfScope prof(UMPR_K_GEMM, 2.0 * M * N * K, s);
+    if (M <= 32) fc_fwd_b16_kernel<1><<<grid, 256, 0, s>>>(p);
+    else if (M <= 64) fc_fwd_b16_kernel<2><<<grid, 256, 0, s>>>(p);
+    else fc_fwd_b16_kernel<4><<<grid, 256, 0, s>>>(p);
+    UMPR_LAUNCH_CHECK("fc_fwd_b16");
+    if (p.split > 1) {
+      const long total = (long)M * N;
+      fc_reduce_kernel<<<cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256), 256, 0, s>>>(ws, p.split, total, N, out, bias, act);
+      UMPR_LAUNCH_CHECK("fc_reduce");
+    }
+    return 0;
+  }
   const int strips = cdiv(N, 32);
   int split = accumulate ? 1 : pick_split(strips, K, 4096);
   while (split > 1 && (size_t)split * M * N * sizeof(float) > ws_bytes) --split;
@@ -249,17 +459,22 @@ int umpr_fc_small_fwd(const float* x, const float* W, const float* bias, float* 
 
 // dx [M][K] = g [M][N] W [N][K]
 int umpr_fc_small_dx(const float* g, const float* W, float* dx, int M, int N, int K, float* ws, size_t ws_bytes,
-                     hipStream_t s) {
+                     hipStream_t s, int bf16) {
   UMPR_REQUIRE(umpr_fc_small_ok(M, N, K), "fc_small_dx: unsupported shape %d x %d x %d", M, N, K);
   const int strips = cdiv(K, 32);
   int split = pick_split(strips, N, 4096);
   while (split > 1 && (size_t)split * M * K * sizeof(float) > ws_bytes) --split;
-  FcParams p{g, W, split > 1 ? ws : dx, nullptr, M, N, K, split, cdiv(cdiv(N, split), 8) * 8, 0};
+  const int gran = bf16 ? 16 : 8;
+  FcParams p{g, W, split > 1 ? ws : dx, nullptr, M, N, K, split, cdiv(cdiv(N, split), gran) * gran, 0};
   p.split = cdiv(N, p.per);
   if (p.split == 1) p.out = dx;
   dim3 grid(cdiv(strips, 4), p.split);
   UmprProfScope prof(UMPR_K_GEMM, 2.0 * M * N * K, s);
-  if (M <= 32) fc_dx_kernel<1><<<grid, 256, 0, s>>>(p);
+  if (bf16) {
+    if (M <= 32) fc_dx_b16_kernel<1><<<grid, 256, 0, s>>>(p);
+    else if (M <= 64) fc_dx_b16_kernel<2><<<grid, 256, 0, s>>>(p);
+    else fc_dx_b16_kernel<4><<<grid, 256, 0, s>>>(p);
+  } else if (M <= 32) fc_dx_kernel<1><<<grid, 256, 0, s>>>(p);
   else if (M <= 64) fc_dx_kernel<2><<<grid, 256, 0, s>>>(p);
   else fc_dx_kernel<4><<<grid, 256, 0, s>>>(p);
   UMPR_LAUNCH_CHECK("fc_dx");
@@ -272,12 +487,13 @@ int umpr_fc_small_dx(const float* g, const float* W, float* dx, int M, int N, in
 }
 
 // dW [N][K] = g [M][N]^T x [M][K]   (overwrites)
-int umpr_fc_small_dw(const float* g, const float* x, float* dW, int M, int N, int K, hipStream_t s) {
+int umpr_fc_small_dw(const float* g, const float* x, float* dW, int M, int N, int K, hipStream_t s, int bf16) {
   UMPR_REQUIRE(umpr_fc_small_ok(M, N, K), "fc_small_dw: unsupported shape %d x %d x %d", M, N, K);
   FcParams p{g, x, dW, nullptr, M, N, K, 1, 0, 0};
   dim3 grid(cdiv(cdiv(K, 128), 4), cdiv(N, 32));
   UmprProfScope prof(UMPR_K_GEMM, 2.0 * M * N * K, s);
-  fc_dw_kernel<<<grid, 256, 0, s>>>(p);
+  if (bf16) fc_dw_b16_kernel<<<grid, 256, 0, s>>>(p);
+  else fc_dw_kernel<<<grid, 256, 0, s>>>(p);
   UMPR_LAUNCH_CHECK("fc_dw");
   return 0;
 }

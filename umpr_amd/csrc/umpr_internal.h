@@ -21,10 +21,10 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream);
 bool umpr_fc_small_ok(int M, int N, int K);
 size_t umpr_fc_small_ws_bytes(int M, int N, int K);
 int umpr_fc_small_fwd(const float* x, const float* W, const float* bias, float* out, int M, int N, int K, int act,
-                      float* ws, size_t ws_bytes, hipStream_t s, int accumulate = 0);
+                      float* ws, size_t ws_bytes, hipStream_t s, int accumulate = 0, int bf16 = 0);
 int umpr_fc_small_dx(const float* g, const float* W, float* dx, int M, int N, int K, float* ws, size_t ws_bytes,
-                     hipStream_t s);
-int umpr_fc_small_dw(const float* g, const float* x, float* dW, int M, int N, int K, hipStream_t s);
+                     hipStream_t s, int bf16 = 0);
+int umpr_fc_small_dw(const float* g, const float* x, float* dW, int M, int N, int K, hipStream_t s, int bf16 = 0);
 
 // small shared launch helpers (util.hip)
 int umpr_fill(float* p, long n, float v, hipStream_t s);

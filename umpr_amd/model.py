@@ -367,6 +367,9 @@ class _VGGFeaturesBF16(torch.autograd.Function):
         return (None, *_grad_returns(ctx.param_objs, grads, direct))
 
 
+_CLS_BF16 = os.environ.get("UMPR_CLS_BF16", "1") != "0"
+
+
 class _VGGClassifier(torch.autograd.Function):
     """Linear(25088,4096)-ReLU-Dropout-Linear(4096,4096)-ReLU-Dropout-Linear(4096,1000) on the pooled features."""
 
@@ -377,7 +380,8 @@ class _VGGClassifier(torch.autograd.Function):
         dev = pool5.device
         ctx.param_objs = params
         ctx.owner = owner
-        ctx.suffix = "_compact" if compact else ""
+        # compact = the bf16 path: its classifier products run on the bf16 matrix pipe too (UMPR_CLS_BF16=0: fp32 MFMA)
+        ctx.suffix = ("_compact_bf16" if _CLS_BF16 else "_compact") if compact else ""
         params = [_c(p) for p in params]
         use_masks = masks_in is not None
         masks = _c(masks_in) if use_masks else torch.empty(2, n, 4096, device=dev, dtype=torch.uint8)
@@ -542,7 +546,7 @@ class VGG16(nn.Module):
     def __init__(self, num_classes=1000, dtype="fp32"):
         super().__init__()
         assert dtype in ("fp32", "bf16"), dtype
-        self.compute_dtype = dtype   # "bf16": conv stack on bf16 MFMA with fp32 accumulation (classifier stays fp32)
+        self.compute_dtype = dtype   # "bf16": conv stack and classifier products on bf16 MFMA, fp32 accumulation
         layers, cin = [], 3
         for v in _VGG_CFG:
             if v == "M":
