@@ -197,8 +197,11 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   // a grid that leaves CUs idle (the text path's [12800 x 128] x 128 products: 100 tiles of 128 x 128) takes smaller
   // tiles: each halving doubles the workgroups in flight
   static const int small_grid = [] { const char* v = getenv("UMPR_GEMM_SMALL_GRID"); return v ? atoi(v) : 384; }();
-  if ((long)cdiv(g.M, BM) * cdiv(g.N, BN) < small_grid && BM == 128) BM = 64;
-  if ((long)cdiv(g.M, BM) * cdiv(g.N, BN) < small_grid && BN == 128) BN = 64;
+  // (not for the deep-K products that split K over workgroups below: there the split fills the chip and a smaller
+  // tile only re-reads more - the [384 x 300] dW_ih products got 16 % slower with 64 x 64 tiles)
+  const bool will_split = g.split_k != 1 && g.K >= 512;
+  if (!will_split && (long)cdiv(g.M, BM) * cdiv(g.N, BN) < small_grid && BM == 128) BM = 64;
+  if (!will_split && (long)cdiv(g.M, BM) * cdiv(g.N, BN) < small_grid && BN == 128) BN = 64;
   const int tm = cdiv(g.M, BM), tn = cdiv(g.N, BN);
   int split = g.split_k;
   if (split <= 0) {  // auto: aim for >= 512 workgroups when K is deep enough to share
