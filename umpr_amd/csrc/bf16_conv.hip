@@ -304,9 +304,15 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
 // The same kernel on v_mfma_f32_16x16x32_bf16: one MFMA covers the whole 32-channel chunk of a tap for a 16 px x 16 ch tile
 // (lane group l >> 4 reads plane l >> 4).  Same LDS traffic and MFMA cycles per step as the 32x32x16 form; the guide
 // measures a higher sustained clock for this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
-template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3>
+// PP (8-wave workgroups only): ping-pong schedule.  The two waves a SIMD holds (w and w + 4) alternate a LOAD phase (DMA
+// issue + the step's 12 fragment reads) and a COMPUTE phase (its 32 MFMAs) separated by s_barrier, the second half of the
+// workgroup running one barrier behind the first, so one wave of every SIMD multiplies while its partner reads
+// (MI355X_MICROARCH.md, "Two waves per SIMD").  Ring safety: a stage is overwritten one full step after its last read and
+// every wave's reads are drained (lgkmcnt(0)) before the barrier that ends its load phase.
+template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3, bool PP = false>
 __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf16_m16_kernel(ConvB16Params p) {
   constexpr int ABL = 0;
+  static_assert(!PP || WP * WC == 8, "ping-pong needs two waves per SIMD in one workgroup");
   constexpr int NW = WP * WC, NT = 64 * NW;
   constexpr bool TWO_D = TR > 0;
   constexpr int BM = TWO_D ? TR * TC : TC;
@@ -421,6 +427,44 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
   wait_vm<(D - 1) * WPW>();
   __syncthreads();
 
+  if (PP) {
+    const bool late = wave >= NW / 2;                   // second-dispatched half: one barrier behind
+    if (late) __builtin_amdgcn_s_barrier();
+    for (int c = 0; c < nchunks; ++c) {
+      const char* pb = reinterpret_cast<const char*>(Pb) + (c & 1) * (PB * 2);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int s = c * 9 + t;
+        // ---- load phase
+        issue_w(s + D);
+        if (t == 0) issue_p(c + 1);
+        const char* wb = reinterpret_cast<const char*>(Wb) + (s % NB) * (WB * 2);
+        const int toff = ((t / 3) - 1) * TS + (t % 3) - 1;
+        bf16x8 a[TCW], b[TPW];
+#pragma unroll
+        for (int i = 0; i < TCW; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wb + wbo + (i * 16) * 16);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pb + pbo[j] + toff * 16);
+        if (t < D) wait_vm<(D - 1) * WPW + PPW>(); else wait_vm<(D - 1) * WPW>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- compute phase
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TCW; ++i)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    wait_vm<0>();
+  } else {
   for (int c = 0; c < nchunks; ++c) {
     const char* pb = reinterpret_cast<const char*>(Pb) + (c & 1) * (PB * 2);
 #pragma unroll
@@ -453,6 +497,7 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
     }
   }
   wait_vm<0>();
+  }
 
   // ---- epilogue: ReLU / mask, zero at pads, bf16; a lane holds channels 4h .. 4h+3 of its pixel: 8-B stores
 #pragma unroll
@@ -1340,6 +1385,11 @@ inline int grid_for(long n, int cap) {
 // 1 (default): v_mfma_f32_16x16x32_bf16 form, 5-10 % faster per layer on MI355X (profiles/r02_k_m16_ab.txt); 0: 32x32x16 form
 const int g_b16_m16 = [] { const char* v = getenv("UMPR_B16_M16"); return v ? atoi(v) : 1; }();
 
+// UMPR_B16_PP: ping-pong schedule in the 8-wave forward / dgrad kernels.  2 (default): where it measured faster - the
+// 256-channel tiles (wave tile 128 x 64, 32 MFMAs per phase: +8-10 %, 512->512@28 1158 TF) and the 1-D 128-channel tiles
+// (+3-5 %); the 2-D 128-channel tiles of the 112 x 112 maps (16 MFMAs per phase) lose 15 % to the second barrier.
+// 1: everywhere, 0: nowhere (profiles/r02_u_pp_ab.txt).
+const int g_b16_pp = [] { const char* v = getenv("UMPR_B16_PP"); return v ? atoi(v) : 2; }();
 const int g_b16_wm16 = [] { const char* v = getenv("UMPR_B16_WM16"); return v ? atoi(v) : 1; }();   // weight gradient likewise (+2 %)
 
 template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3, int ABL = 0>
@@ -1351,7 +1401,15 @@ void launch_conv(ConvB16Params p, hipStream_t s) {
   long blocks;
   if (p.nct <= 8 && (8 % p.nct) == 0) { const int g = 8 / p.nct; blocks = ((p.ntp + g - 1) / g) * 8; }
   else blocks = ((p.ntp + 7) / 8) * 8 * p.nct;
-  if (g_b16_m16 && ABL == 0) conv_bf16_m16_kernel<W, TR, TC, BN, WP, WC, D><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
+  if (g_b16_m16 && ABL == 0) {
+    if constexpr (WP * WC == 8) {
+      if (g_b16_pp == 1 || (g_b16_pp == 2 && (BN == 256 || TR == 0))) {
+        conv_bf16_m16_kernel<W, TR, TC, BN, WP, WC, D, true><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
+        return;
+      }
+    }
+    conv_bf16_m16_kernel<W, TR, TC, BN, WP, WC, D><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
+  }
   else conv_bf16_kernel<W, TR, TC, BN, WP, WC, D, ABL><<<dim3((unsigned)blocks), 64 * WP * WC, 0, s>>>(p);
 }
 
