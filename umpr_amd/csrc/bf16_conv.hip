@@ -1643,6 +1643,34 @@ int umpr_conv1_bf16_fwd(const float* x, const float* w, const float* bias, void*
   return 0;
 }
 
+// dw[co][c][tap] (+)= sum over the splits of slab[split][tap][co][c], db likewise: one wave per output element (the
+// generic reduce walks the 512 slabs with one thread per element: 138 us for 1792 outputs), fixed order
+__global__ __launch_bounds__(256) void wgrad1_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                            int splits, float* __restrict__ dw, float* __restrict__ db,
+                                                            int accumulate) {
+  constexpr int per = 9 * 64 * 3;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= per + (bslab ? 64 : 0)) return;
+  float v = 0.f;
+  if (i < per) {
+    for (int q = lane; q < splits; q += 64) v += slab[(long)q * per + i];
+  } else {
+    for (int q = lane; q < splits; q += 64) v += bslab[(long)q * 64 + (i - per)];
+  }
+  v = wave_sum(v);
+  if (lane == 0) {
+    if (i < per) {
+      const int c = i % 3, r = i / 3, co = r % 64, t = r / 64;
+      float* d = dw + ((long)co * 3 + c) * 9 + t;
+      *d = accumulate ? *d + v : v;
+    } else {
+      float* d = db + (i - per);
+      *d = accumulate ? *d + v : v;
+    }
+  }
+}
+
 constexpr int kWgrad1Splits = 512;
 size_t umpr_conv1_bf16_wgrad_ws_bytes() { return (size_t)kWgrad1Splits * (9 * 64 * 3 + 64) * sizeof(float) + 1024; }
 
@@ -1658,7 +1686,9 @@ int umpr_conv1_bf16_wgrad(const void* dy, const float* x, float* dw, float* db, 
     conv1_bf16_wgrad_kernel<<<kWgrad1Splits, 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("conv1_bf16_wgrad");
-  return umpr_wgrad_reduce(ws, bslab, kWgrad1Splits, 64, 3, dw, db, accumulate, s);
+  wgrad1_reduce_kernel<<<(9 * 64 * 3 + 64 + 3) / 4, 256, 0, s>>>(ws, bslab, kWgrad1Splits, dw, db, accumulate);
+  UMPR_LAUNCH_CHECK("wgrad1_reduce");
+  return 0;
 }
 
 // guards of up to 20 CB8-PF tensors (start-of-plane pointers) in one launch
