@@ -356,7 +356,7 @@ def main():
             achieved = (work / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
             roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS, "traffic": None,
-                    "kernel": "gru_fwd_kernel / gru_bwd_kernel (recurrent part of the packed BiGRU): algorithmic bytes "
+                    "kernel": "gru_fwd16_kernel / gru_bwd16_kernel (recurrent part of the packed BiGRU, 16-sequence tiles): algorithmic bytes "
                               "(gx, out, saved gates, dgx) / HIP-event time.  The kernel is latency-bound - a chain of "
                               "<= 20 dependent steps per sequence tile - not bandwidth-bound, so the fraction is small "
                               "by construction", "launches": n, "avg_launch_ms": ms / max(n, 1),
