@@ -129,12 +129,11 @@ int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,
     float* wst = gx + (size_t)N * L * 384 + (size_t)umpr_gru_tiles(N) * (2 * G3 * H + 2 * 2 * G3);   // the dW_ih slab area
     float* bst = wst + (size_t)2 * G3 * E;
     const hipStream_t s = S(stream);
-    if (hipMemcpyAsync(wst, w_ih_f, (size_t)G3 * E * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(wst + (size_t)G3 * E, w_ih_r, (size_t)G3 * E * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(bst, b_ih_f, G3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(bst + G3, b_ih_r, G3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-      umpr_set_error("embed_gru: stacking the input weights failed");
-      return -2;
+    {  // stack the two directions' input weights and biases: one launch
+      const float* src[4] = {w_ih_f, w_ih_r, b_ih_f, b_ih_r};
+      float* dst[4] = {wst, wst + (size_t)G3 * E, bst, bst + G3};
+      const long cnt[4] = {(long)G3 * E, (long)G3 * E, G3, G3};
+      if (int rc = umpr_multi_copy(src, dst, cnt, nullptr, 4, s)) return rc;
     }
     UmprGemm g;
     g.A = emb; g.lda = E; g.gatherA = ids; g.B = wst; g.ldb = E; g.transB = true;
@@ -170,10 +169,15 @@ int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E, co
   float* dbih[2] = {db_ih_f, db_ih_r};
   float* dbhh[2] = {db_hh_f, db_hh_r};
   float* dwih[2] = {dw_ih_f, dw_ih_r};
-  for (int d = 0; d < 2; ++d) {
-    if (int rc = umpr_colsum_rows(wslab + (size_t)d * G3 * H, tiles, G3 * H, 2 * G3 * H, dwhh[d], accumulate, S(stream))) return rc;
-    if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3, tiles, G3, 4 * G3, dbih[d], accumulate, S(stream))) return rc;
-    if (int rc = umpr_colsum_rows(bslab + (size_t)d * 2 * G3 + G3, tiles, G3, 4 * G3, dbhh[d], accumulate, S(stream))) return rc;
+  {  // the six per-tile slab reductions (dW_hh, db_ih, db_hh of both directions): one launch
+    const float* src[6]; float* dst[6]; int rows[6]; long cols[6], rs[6]; int acc[6];
+    for (int d = 0; d < 2; ++d) {
+      src[3 * d] = wslab + (size_t)d * G3 * H;            dst[3 * d] = dwhh[d];     cols[3 * d] = G3 * H;     rs[3 * d] = 2 * G3 * H;
+      src[3 * d + 1] = bslab + (size_t)d * 2 * G3;        dst[3 * d + 1] = dbih[d]; cols[3 * d + 1] = G3;     rs[3 * d + 1] = 4 * G3;
+      src[3 * d + 2] = bslab + (size_t)d * 2 * G3 + G3;   dst[3 * d + 2] = dbhh[d]; cols[3 * d + 2] = G3;     rs[3 * d + 2] = 4 * G3;
+    }
+    for (int q = 0; q < 6; ++q) { rows[q] = tiles; acc[q] = accumulate; }
+    if (int rc = umpr_multi_colsum_rows(src, rows, cols, rs, dst, acc, 6, S(stream))) return rc;
   }
   {  // [dW_ih_f ; dW_ih_r] [384][E] = dgx^T emb[ids]: one split-K gather-GEMM for both directions, then rows 0..191 /
      // 192..383 are copied (or added) to their parameters' gradients
@@ -183,8 +187,10 @@ int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E, co
     g.C = stacked; g.ldc = E; g.M = 2 * G3; g.N = E; g.K = N * L; g.split_k = 0; g.ws = kslab;
     g.ws_bytes = (size_t)128 * G3 * E * sizeof(float);
     if (int rc = umpr_gemm(g, S(stream))) return rc;
-    if (int rc = umpr_copy_or_add(stacked, dwih[0], (long)G3 * E, accumulate, S(stream))) return rc;
-    if (int rc = umpr_copy_or_add(stacked + (size_t)G3 * E, dwih[1], (long)G3 * E, accumulate, S(stream))) return rc;
+    const float* csrc[2] = {stacked, stacked + (size_t)G3 * E};
+    const long ccnt[2] = {(long)G3 * E, (long)G3 * E};
+    const int cacc[2] = {accumulate, accumulate};
+    if (int rc = umpr_multi_copy(csrc, dwih, ccnt, cacc, 2, S(stream))) return rc;
   }
   return 0;
 }

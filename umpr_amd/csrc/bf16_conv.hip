@@ -78,7 +78,27 @@ struct ConvB16Params {
   long rows;                     // map rows incl. zero rows
   int relu, nct;
   long ntp;                      // pixel tiles
+  long zlead, ztail;             // > 0: the kernel also zeroes the output's guards (zlead pixels before pixel 0, ztail
+                                 // after ptot, per plane), a slice per pixel tile - saves a launch per layer in the backward
 };
+
+// guard pixels [g0, g1) of the zlead + ztail guard pixels of each of this channel tile's planes
+template <int BN, int NT>
+__device__ __forceinline__ void zero_guard_slice(const ConvB16Params& p, int ct, long pt, int tid) {
+  const long G = p.zlead + p.ztail;
+  if (G <= 0) return;
+  const long g0 = pt * G / p.ntp, g1 = (pt + 1) * G / p.ntp;
+  constexpr int PL = BN / 8;
+  bf16x8 z;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) z[q] = (bf16_t)0.f;
+  for (long e = tid; e < (g1 - g0) * PL; e += NT) {
+    const long gp = g0 + e / PL;
+    const int pl = (int)(e % PL);
+    const long P = gp < p.zlead ? gp - p.zlead : p.ptot + (gp - p.zlead);
+    *reinterpret_cast<bf16x8*>(p.y + ((long)(ct * PL + pl) * p.yps + P) * 8) = z;
+  }
+}
 
 // W: map width.  TR > 0: 2-D tile of TR rows x TC real columns; TR == 0: 1-D tile of TC consecutive flat pixels.
 // BN output channels per workgroup; WP x WC waves (pixels x channels).
@@ -286,6 +306,7 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
       }
     }
   }
+  zero_guard_slice<BN, NT>(p, ct, pt, tid);
   if (TWO_D && ctile == 0) {   // column 0 (the zero pad) of this tile's rows: no tile computes it
     const long row0 = Q0 / RW;
     for (int e = tid; e < TR * (BN / 8); e += NT) {
@@ -535,6 +556,7 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
       *reinterpret_cast<bf16x4*>(p.y + o) = out;
     }
   }
+  zero_guard_slice<BN, NT>(p, ct, pt, tid);
   if (TWO_D && ctile == 0) {   // column 0 (the zero pad) of this tile's rows: no tile computes it
     const long row0 = Q0 / RW;
     for (int e = tid; e < TR * (BN / 8); e += NT) {
@@ -1075,11 +1097,14 @@ __global__ __launch_bounds__(256) void bias_grad_bf16_kernel(const bf16_t* __res
 // layout conversion, pooling, guards
 // fp32 NCHW -> bf16 CB8-PF (zero pads written; channels past C are zero)
 __global__ void nchw_to_cb8_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long yps, int C, int H, int W,
-                                   long ptot) {
+                                   long ptot, long lead) {
   const int RW = W + 1;
   const int cb = blockIdx.y;
-  for (long P = blockIdx.x * (long)blockDim.x + threadIdx.x; P < ptot; P += (long)gridDim.x * blockDim.x) {
-    const long row = P / RW; const int col = (int)(P - row * RW);
+  // Q runs over the whole plane [0, yps): pixel P = Q - lead; the guards (P < 0, P >= ptot) are written as zeros here
+  for (long Q = blockIdx.x * (long)blockDim.x + threadIdx.x; Q < yps; Q += (long)gridDim.x * blockDim.x) {
+    const long P = Q - lead;
+    const bool inside = P >= 0 && P < ptot;
+    const long row = inside ? P / RW : 0; const int col = inside ? (int)(P - row * RW) : 0;
     const int rr = (int)(row % (H + 1));
     bf16x8 v;
 #pragma unroll
@@ -1176,11 +1201,15 @@ __global__ void maxpool2_bf16_fwd_kernel(const bf16_t* __restrict__ x, long xps,
 // gx = pool backward routed to the FIRST maximum of each window (order (0,0),(0,1),(1,0),(1,1), like the fp32 kernel),
 // zero where that maximum is not > 0 (ReLU of the activation that fed the pool); one thread per INPUT pixel, pads zero
 __global__ void maxpool2_bf16_bwd_relu_kernel(const bf16_t* __restrict__ x, long xps, const bf16_t* __restrict__ gy,
-                                              long gps, bf16_t* __restrict__ gx, long gxps, int H, int W, long ptot_in) {
+                                              long gps, bf16_t* __restrict__ gx, long gxps, int H, int W, long ptot_in,
+                                              long lead) {
   const int Ho = H / 2, Wo = W / 2, RWo = Wo + 1, RWi = W + 1;
   const int cb = blockIdx.y;
-  for (long P = blockIdx.x * (long)blockDim.x + threadIdx.x; P < ptot_in; P += (long)gridDim.x * blockDim.x) {
-    const long row = P / RWi; const int col = (int)(P - row * RWi);
+  // Q runs over the whole plane of gx: pixel P = Q - lead; its guards are written as zeros here
+  for (long Q = blockIdx.x * (long)blockDim.x + threadIdx.x; Q < gxps; Q += (long)gridDim.x * blockDim.x) {
+    const long P = Q - lead;
+    const bool inside = P >= 0 && P < ptot_in;
+    const long row = inside ? P / RWi : 0; const int col = inside ? (int)(P - row * RWi) : 0;
     const int rr = (int)(row % (H + 1));
     bf16x8 out;
 #pragma unroll
@@ -1521,11 +1550,9 @@ int umpr_conv_bf16_run(const void* x, const float* w, int transposed, const floa
     UMPR_LAUNCH_CHECK("pack_weights_bf16");
   }
   bf16_t* y0 = static_cast<bf16_t*>(y);
-  if (zero_guards) {
-    zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), M / 8), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);
-    UMPR_LAUNCH_CHECK("zero_guards");
-  }
   ConvB16Params p;
+  p.zlead = zero_guards ? g.lead : 0;
+  p.ztail = zero_guards ? g.ps - g.lead - g.ptot : 0;
   p.x = static_cast<const bf16_t*>(x) + g.lead * 8; p.xps = g.ps;
   p.wp = wp; p.bias = bias;
   p.mask = mask ? static_cast<const bf16_t*>(mask) + g.lead * 8 : nullptr; p.mps = g.ps;
@@ -1594,8 +1621,7 @@ int umpr_wgrad_bf16_run(const void* dy, const void* x, float* dw, float* db, con
 int umpr_nchw_to_cb8(const float* x, void* y, const UmprPF& g, int C, hipStream_t s) {
   bf16_t* y0 = static_cast<bf16_t*>(y);
   const int planes = (C + 7) / 8;
-  zero_guards_kernel<<<dim3(grid_for(g.ps - g.ptot, 64), planes), 256, 0, s>>>(y0, g.ps, g.lead, g.ptot);
-  nchw_to_cb8_kernel<<<dim3(grid_for(g.ptot, 4096), planes), 256, 0, s>>>(x, y0 + g.lead * 8, g.ps, C, g.H, g.W, g.ptot);
+  nchw_to_cb8_kernel<<<dim3(grid_for(g.ps, 4096), planes), 256, 0, s>>>(x, y0 + g.lead * 8, g.ps, C, g.H, g.W, g.ptot, g.lead);
   UMPR_LAUNCH_CHECK("nchw_to_cb8");
   return 0;
 }
@@ -1621,10 +1647,9 @@ int umpr_maxpool2_bf16_fwd_run(const void* x, void* y, const UmprPF& gi, const U
 int umpr_maxpool2_bf16_bwd_run(const void* x, const void* gy, void* gx, const UmprPF& gi, const UmprPF& go, int C,
                                hipStream_t s) {
   bf16_t* g0 = static_cast<bf16_t*>(gx);
-  zero_guards_kernel<<<dim3(grid_for(gi.ps - gi.ptot, 64), C / 8), 256, 0, s>>>(g0, gi.ps, gi.lead, gi.ptot);
-  maxpool2_bf16_bwd_relu_kernel<<<dim3(grid_for(gi.ptot, 4096), C / 8), 256, 0, s>>>(
+  maxpool2_bf16_bwd_relu_kernel<<<dim3(grid_for(gi.ps, 4096), C / 8), 256, 0, s>>>(
       static_cast<const bf16_t*>(x) + gi.lead * 8, gi.ps, static_cast<const bf16_t*>(gy) + go.lead * 8, go.ps,
-      g0 + gi.lead * 8, gi.ps, gi.H, gi.W, gi.ptot);
+      g0 + gi.lead * 8, gi.ps, gi.H, gi.W, gi.ptot, gi.lead);
   UMPR_LAUNCH_CHECK("maxpool2_bf16_bwd");
   return 0;
 }

@@ -28,6 +28,9 @@ int umpr_fc_small_dw(const float* g, const float* x, float* dW, int M, int N, in
 
 // small shared launch helpers (util.hip)
 int umpr_fill(float* p, long n, float v, hipStream_t s);
+int umpr_multi_copy(const float* const* src, float* const* dst, const long* n, const int* accumulate, int nseg, hipStream_t s);
+int umpr_multi_colsum_rows(const float* const* src, const int* rows, const long* cols, const long* row_stride, float* const* dst,
+                           const int* accumulate, int nseg, hipStream_t s);
 int umpr_copy_or_add(const float* src, float* dst, long n, int accumulate, hipStream_t s);   // dst (+)= src
 
 // visual head + fusion + losses (text_ops.hip)

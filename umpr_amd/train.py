@@ -50,7 +50,8 @@ def train_step(model, opt: FusedAdam, batch, world=1, reducer=None):
         opt.step(grad_scale=1.0 / n_active)
         return torch.empty(0, device=dev), torch.zeros((), device=dev)
     pred, loss = model(*batch)
-    loss = loss.mean()
+    if loss.dim() > 0:               # main.py:34 takes the mean over DataParallel's per-replica losses; one process per
+        loss = loss.mean()           # GPU returns a scalar, whose mean is itself (and costs five tiny kernels)
     opt.zero_grad()
     opt.arm_early(1.0 / n_active)    # the classifier slice may be updated as soon as its gradients are final
     loss.backward()
