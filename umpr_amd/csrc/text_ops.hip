@@ -183,48 +183,43 @@ struct CnetHeadFwdParams {
   int S, L, KC, V;
 };
 
-__global__ __launch_bounds__(256) void cnet_head_fwd_kernel(CnetHeadFwdParams p) {
-  extern __shared__ float sm[];  // cm[4][KC], fin[4][V]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+// one wave per sentence over the whole grid (was: one workgroup per sample walking S / 4 sentences per wave - 64
+// workgroups reading the 20 MB of Y at 0.2 TB/s); the per-sample sum over sentences is cnet_final_kernel
+__global__ __launch_bounds__(256) void cnet_head_fwd_kernel(CnetHeadFwdParams p, long nsent) {
+  extern __shared__ float sm[];  // cm[4][KC]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long sent = (long)blockIdx.x * 4 + wave;
+  if (sent >= nsent) return;
   float* cm = sm + wave * p.KC;
-  float* fin = sm + 4 * p.KC;
-  for (int v = lane; v < p.V; v += 64) fin[wave * p.V + v] = 0.f;
-  __syncthreads();
-  for (int s0 = 0; s0 < p.S; s0 += 4) {
-    const int s = s0 + wave;
-    const bool on = s < p.S;
-    const long sent = (long)b * p.S + s;
-    if (on) {
-      const float* Y = p.Y + sent * p.L * p.KC;
-      for (int k = lane; k < p.KC; k += 64) {
-        float m = Y[k]; int a = 0;
-        for (int l = 1; l < p.L; ++l) {
-          const float y = Y[l * p.KC + k];
-          if (y > m) { m = y; a = l; }
-        }
-        cm[k] = m;
-        p.cmax[sent * p.KC + k] = m; p.argl[sent * p.KC + k] = a;
-      }
+  const float* Y = p.Y + sent * p.L * p.KC;
+  for (int k = lane; k < p.KC; k += 64) {
+    float m = Y[k]; int a = 0;
+    for (int l = 1; l < p.L; ++l) {
+      const float y = Y[l * p.KC + k];
+      if (y > m) { m = y; a = l; }
     }
-    __syncthreads();
-    if (on) {
-      for (int v = 0; v < p.V; ++v) {
-        float a = 0.f;
-        for (int k = lane; k < p.KC; k += 64) a += p.Wl[v * p.KC + k] * cm[k];
-        a = wave_sum(a) + p.bl[v];
-        const float sg = sigmoidf_(a);
-        const float vp = sg < p.thr ? 0.f : sg;
-        if (lane == 0) {
-          p.sp[sent * p.V + v] = sg; p.view_p[sent * p.V + v] = vp;
-          fin[wave * p.V + v] += vp * vp;
-        }
-      }
-    }
-    __syncthreads();
+    cm[k] = m;
+    p.cmax[sent * p.KC + k] = m; p.argl[sent * p.KC + k] = a;
   }
-  __syncthreads();
-  for (int v = tid; v < p.V; v += 256)
-    p.final_[(long)b * p.V + v] = fin[v] + fin[p.V + v] + fin[2 * p.V + v] + fin[3 * p.V + v];
+  // cm is written and read by this wave only: a wave executes in lock-step, no barrier needed
+  for (int v = 0; v < p.V; ++v) {
+    float a = 0.f;
+    for (int k = lane; k < p.KC; k += 64) a += p.Wl[v * p.KC + k] * cm[k];
+    a = wave_sum(a) + p.bl[v];
+    const float sg = sigmoidf_(a);
+    const float vp = sg < p.thr ? 0.f : sg;
+    if (lane == 0) { p.sp[sent * p.V + v] = sg; p.view_p[sent * p.V + v] = vp; }
+  }
+}
+
+// final[b][v] = sum_s view_p[b][s][v]^2   (fixed order)
+__global__ void cnet_final_kernel(const float* __restrict__ view_p, float* __restrict__ final_, int S, int V) {
+  const int b = blockIdx.x;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) { const float vp = view_p[((long)b * S + s) * V + v]; a += vp * vp; }
+    final_[(long)b * V + v] = a;
+  }
 }
 
 struct CnetHeadBwdParams {
@@ -823,8 +818,11 @@ int umpr_cnet_head_fwd_impl(const float* X, const float* Wc, const float* bc, co
   g.K = D * KS; g.bias = bc; g.bias_mode = 1; g.act = UMPR_ACT_RELU;
   if (int rc = umpr_gemm(g, s)) return rc;
   CnetHeadFwdParams p{Y, Wl, bl, thr, cmax, argl, sp, view_p, final_, S, L, KC, V};
-  cnet_head_fwd_kernel<<<B, 256, (4 * KC + 4 * V) * sizeof(float), s>>>(p);
+  const long nsent = (long)B * S;
+  cnet_head_fwd_kernel<<<(unsigned)((nsent + 3) / 4), 256, 4 * KC * sizeof(float), s>>>(p, nsent);
   UMPR_LAUNCH_CHECK("cnet_head_fwd");
+  cnet_final_kernel<<<B, 64, 0, s>>>(view_p, final_, S, V);
+  UMPR_LAUNCH_CHECK("cnet_final");
   return 0;
 }
 
