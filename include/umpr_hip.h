@@ -35,6 +35,12 @@ int umpr_gemm_f32(const float* A, long lda, int transA, const float* B, long ldb
                   int M, int N, int K, const float* bias, int bias_mode, int act, int accumulate, float alpha,
                   float* ws, size_t ws_bytes, void* stream);
 
+/* Mixed precision for the GEMM-shaped products of the text path (BASELINE.json configs[4]; not in the reference, which
+ * would get it from torch.autocast): while set on the calling host thread, every product the library issues through this
+ * GEMM (GRU input projections, co-attention / S-Net / C-Net projections and their gradients) rounds its operands to bf16 on
+ * the way into LDS and runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Set it around a call, clear it after. */
+int umpr_set_gemm_bf16(int on);
+
 /* ---- K1-K3: embedding lookup + bidirectional packed GRU + the reference's double un-sort ---------------------
  * Replaces nn.Embedding (model.py:262-264) + ImprovedRnn.forward (model.py:12-21) for one review tensor.
  * ids [N*L] int64; emb [vocab][E]; GRU weights in nn.GRU layout (gate order r,z,n): w_ih [192][E], w_hh [192][64],

@@ -205,6 +205,39 @@ def test_review_head_bf16_scores(L, dev, B, S, Lm, m_scale):
     assert e_g <= 0.2 and (e_m <= 0.2 or float(res[False][2].norm()) < 1e-6)
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb,ws", [(300, 384, 300, 0, 1, 0), (1000, 128, 128, 0, 0, 0), (384, 300, 5000, 1, 0, 1),
+                                            (64, 64, 40, 0, 1, 0), (130, 70, 52, 1, 1, 0)])
+def test_gemm_bf16_operands(L, dev, M, N, K, ta, tb, ws):
+    """umpr_gemm_f32 under umpr_set_gemm_bf16(1) (the text path's products in bf16 mode) against the float64 product of the
+    bf16-rounded operands, all four operand layouts, ragged edges, split-K: only the fp32 summation differs."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).to(dev)
+    B = torch.randn((N, K) if tb else (K, N), generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    wsb = 64 * M * N * 4 if ws else 0
+    wst = torch.empty(max(wsb // 4, 1), device=dev)
+    L.call("umpr_set_gemm_bf16", 1)
+    try:
+        L.call("umpr_gemm_f32", A, A.shape[1], ta, B, B.shape[1], tb, C, N, M, N, K, bias, 1, 0, 0, 1.0,
+               wst if ws else None, wsb, st())
+    finally:
+        L.call("umpr_set_gemm_bf16", 0)
+    opA = q(A).double().t() if ta else q(A).double()
+    opB = q(B).double().t() if tb else q(B).double()
+    ref = (opA @ opB + bias.double()).float()
+    e = rel_l2(C.cpu(), ref.cpu())
+    log(f"gemm bf16 operands M{M} N{N} K{K} ta{ta} tb{tb} splitk{ws}: relL2 {e:.2e}")
+    assert torch.isfinite(C).all() and e <= 1e-5
+    # and the switch is off again: the same call now gives the fp32 product
+    L.call("umpr_gemm_f32", A, A.shape[1], ta, B, B.shape[1], tb, C, N, M, N, K, bias, 1, 0, 0, 1.0,
+           wst if ws else None, wsb, st())
+    opA = A.double().t() if ta else A.double()
+    opB = B.double().t() if tb else B.double()
+    e32 = rel_l2(C.cpu(), (opA @ opB + bias.double()).float().cpu())
+    assert e32 <= 1e-5, e32
+
+
 class _QLinear(torch.autograd.Function):
     """nn.Linear with every matrix-product operand rounded to bf16 and fp32 accumulation: what the bf16 classifier
     kernels compute (bias and bias gradient stay fp32).  The products run in float64 so that the reference does not

@@ -90,6 +90,7 @@ SIGNATURES = {
     "umpr_bce_head_bwd": ("plpppppiiplpppzp", "i"),
     "umpr_adam_step": ("ppppldddddldp", "i"),
     "umpr_debug_poison_lds": ("pp", "i"),
+    "umpr_set_gemm_bf16": ("i", "i"),
     "umpr_profile_enable": ("i", "i"),
     "umpr_profile_reset": ("", "i"),
     "umpr_profile_read": ("ippp", "i"),
@@ -98,6 +99,9 @@ SIGNATURES = {
 
 class UmprHipError(RuntimeError):
     pass
+
+
+GEMM_B16 = False   # set by umpr_amd.model around the text path's calls in bf16 mode (umpr_set_gemm_bf16)
 
 
 class _Lib:
@@ -127,7 +131,14 @@ class _Lib:
                 conv.append(None)
             else:
                 conv.append(a)
-        rc = self.fn[name](*conv)
+        if GEMM_B16:
+            self.fn["umpr_set_gemm_bf16"](1)
+            try:
+                rc = self.fn[name](*conv)
+            finally:
+                self.fn["umpr_set_gemm_bf16"](0)
+        else:
+            rc = self.fn[name](*conv)
         if rc != 0:
             raise UmprHipError(f"{name} failed (rc={rc}): {self.last_error()}")
 

@@ -32,15 +32,23 @@ struct GemmParams {
   int vecA, vecB;
 };
 
-template <int BM, int BN, bool TA, bool TB>
+// B16 (mixed-precision mode, text path): operands stay fp32 in memory and are rounded to bf16 when a stage is written to
+// LDS ([row][16 k] images, 48-B rows); one v_mfma_f32_32x32x16_bf16 per 32 x 32 tile and stage instead of eight fp32 MFMAs,
+// fp32 accumulation and epilogue unchanged.  The kernel is then bound by its global loads, not by the matrix pipe.
+typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, bool TA, bool TB, bool B16 = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   using LA = TileRegs<BM, !TA>;  // A non-trans is k-contiguous
   using LB = TileRegs<BN, TB>;   // B trans is k-contiguous
   constexpr int LDA = LA::LD, LDB = LB::LD;
   constexpr int WTM = BM / 2, WTN = BN / 2;  // 2x2 waves
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+  constexpr int L16 = LA::LDB16;
+  __shared__ __attribute__((aligned(16))) float As[B16 ? 1 : 2][B16 ? 4 : BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[B16 ? 1 : 2][B16 ? 4 : BK * LDB];
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[B16 ? 2 : 1][B16 ? BM * L16 : 8];
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[B16 ? 2 : 1][B16 ? BN * L16 : 8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -66,8 +74,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   if (nt > 0) {
     ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg, kend, p.vecA, tid);
     rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg, kend, p.vecB, tid);
-    ra.store(As[0], tid);
-    rb.store(Bs[0], tid);
+    if (B16) { ra.store_b16(Ah[0], tid); rb.store_b16(Bh[0], tid); }
+    else { ra.store(As[0], tid); rb.store(Bs[0], tid); }
   }
   __syncthreads();
   const int l31 = lane & 31, kh = lane >> 5;
@@ -87,6 +95,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     if (t + 1 < nt) {
       ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg + (t + 1) * BK, kend, p.vecA, tid);
       rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg + (t + 1) * BK, kend, p.vecB, tid);
+    }
+    if constexpr (B16) {
+      gemm_bf16x8 ah[TM], bh[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const gemm_bf16x8*>(&Ah[cur][(wm * WTM + i * 32 + l31) * L16 + 8 * kh]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const gemm_bf16x8*>(&Bh[cur][(wn * WTN + j * 32 + l31) * L16 + 8 * kh]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      if (t + 1 < nt) { ra.store_b16(Ah[cur ^ 1], tid); rb.store_b16(Bh[cur ^ 1], tid); }
+      __syncthreads();
+      continue;
     }
     const float* as = As[cur] + wm * WTM + l31;
     const float* bs = Bs[cur] + wn * WTN + l31;
@@ -170,6 +192,14 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
 }
 
 template <int BM, int BN>
+void launch_tile_b16(const GemmParams& p, bool ta, bool tb, dim3 grid, hipStream_t s) {
+  if (!ta && !tb) gemm_f32_kernel<BM, BN, false, false, true><<<grid, 256, 0, s>>>(p);
+  else if (!ta && tb) gemm_f32_kernel<BM, BN, false, true, true><<<grid, 256, 0, s>>>(p);
+  else if (ta && !tb) gemm_f32_kernel<BM, BN, true, false, true><<<grid, 256, 0, s>>>(p);
+  else gemm_f32_kernel<BM, BN, true, true, true><<<grid, 256, 0, s>>>(p);
+}
+
+template <int BM, int BN>
 void launch_tile(const GemmParams& p, bool ta, bool tb, dim3 grid, hipStream_t s) {
   if (!ta && !tb) gemm_f32_kernel<BM, BN, false, false><<<grid, 256, 0, s>>>(p);
   else if (!ta && tb) gemm_f32_kernel<BM, BN, false, true><<<grid, 256, 0, s>>>(p);
@@ -178,6 +208,10 @@ void launch_tile(const GemmParams& p, bool ta, bool tb, dim3 grid, hipStream_t s
 }
 
 }  // namespace
+
+// per host thread: products issued while it is set round their operands to bf16 (umpr_set_gemm_bf16, mixed-precision mode)
+static thread_local int t_gemm_b16 = 0;
+void umpr_gemm_set_b16(int on) { t_gemm_b16 = on; }
 
 int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   UMPR_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
@@ -232,7 +266,12 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   p.split_k = split; p.k_per_split = kps; p.ws = g.ws;
   dim3 grid(tn, tm, split);
   UmprProfScope prof(UMPR_K_GEMM, 2.0 * g.M * g.N * g.K, stream);
-  if (BM == 128 && BN == 128) launch_tile<128, 128>(p, g.transA, g.transB, grid, stream);
+  if (t_gemm_b16) {
+    if (BM == 128 && BN == 128) launch_tile_b16<128, 128>(p, g.transA, g.transB, grid, stream);
+    else if (BM == 64 && BN == 128) launch_tile_b16<64, 128>(p, g.transA, g.transB, grid, stream);
+    else if (BM == 128 && BN == 64) launch_tile_b16<128, 64>(p, g.transA, g.transB, grid, stream);
+    else launch_tile_b16<64, 64>(p, g.transA, g.transB, grid, stream);
+  } else if (BM == 128 && BN == 128) launch_tile<128, 128>(p, g.transA, g.transB, grid, stream);
   else if (BM == 64 && BN == 128) launch_tile<64, 128>(p, g.transA, g.transB, grid, stream);
   else if (BM == 128 && BN == 64) launch_tile<128, 64>(p, g.transA, g.transB, grid, stream);
   else launch_tile<64, 64>(p, g.transA, g.transB, grid, stream);

@@ -15,6 +15,7 @@ struct UmprGemm {
   int split_k = 1;                   // 0 = auto (needs ws)
   float* ws = nullptr; size_t ws_bytes = 0;
 };
+void umpr_gemm_set_b16(int on);
 int umpr_gemm(const UmprGemm& g, hipStream_t stream);
 
 // fc_small.hip - batch-sized fully connected layers (register-streaming fp32 MFMA, no LDS)

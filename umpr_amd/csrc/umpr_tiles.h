@@ -74,5 +74,31 @@ struct TileRegs {
       }
     }
   }
+
+  // bf16 stage image for v_mfma_f32_32x32x16_bf16: S[row][LDB16] bf16, row = the tile's m / n index, 16 k per row (32 B)
+  // padded to 48 B - 16 lanes x ds_read_b128 at a 48-B stride touch 64 distinct banks
+  static constexpr int LDB16 = 24;
+  __device__ __forceinline__ void store_b16(__bf16* __restrict__ S, int tid) const {
+    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int e = tid + v * 256;
+      const unsigned m = okmask >> (4 * v);
+      const float4 val = make_float4((m & 1) ? r[v].x : 0.f, (m & 2) ? r[v].y : 0.f, (m & 4) ? r[v].z : 0.f, (m & 8) ? r[v].w : 0.f);
+      if (KCONTIG) {
+        const int mn = e >> 2, kq = e & 3;
+        bf16x4_ o;
+        o[0] = (__bf16)val.x; o[1] = (__bf16)val.y; o[2] = (__bf16)val.z; o[3] = (__bf16)val.w;
+        *reinterpret_cast<bf16x4_*>(&S[mn * LDB16 + 4 * kq]) = o;
+      } else {
+        constexpr int QPR = TILE / 4;
+        const int k = e / QPR, q = e % QPR;
+        S[(4 * q + 0) * LDB16 + k] = (__bf16)val.x;
+        S[(4 * q + 1) * LDB16 + k] = (__bf16)val.y;
+        S[(4 * q + 2) * LDB16 + k] = (__bf16)val.z;
+        S[(4 * q + 3) * LDB16 + k] = (__bf16)val.w;
+      }
+    }
+  }
 };
 

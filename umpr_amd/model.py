@@ -16,6 +16,7 @@ import os
 import torch
 from torch import nn
 
+from . import _lib as _lib_mod
 from ._lib import Workspace, lib, stream_ptr
 
 TEXT_STREAM = os.environ.get("UMPR_TEXT_STREAM", "1") != "0"   # text path on side streams beside the VGG stack
@@ -65,12 +66,46 @@ def _grad_returns(params, dst, direct):
 
 
 # --------------------------------------------------------------------------------------------- K1-K3
+# Mixed precision of the text path's GEMM-shaped products (bf16 mode only; UMPR_TEXT_BF16=0 keeps them on the fp32 MFMA
+# kernels): UMPR.forward publishes the mode, every text Function records it at forward time and brackets its library calls
+# with umpr_set_gemm_bf16 (through _lib.GEMM_B16) in forward AND in its backward, whichever thread autograd runs that on.
+_TEXT_BF16 = os.environ.get("UMPR_TEXT_BF16", "1") != "0"
+_MODE = {"b16": False}
+
+
+class _b16_products:
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _lib_mod.GEMM_B16
+        _lib_mod.GEMM_B16 = self.on
+
+    def __exit__(self, *exc):
+        _lib_mod.GEMM_B16 = self.prev
+
+
+def _b16_forward(f):
+    def w(ctx, *a):
+        ctx.b16 = _MODE["b16"]
+        with _b16_products(ctx.b16):
+            return f(ctx, *a)
+    return staticmethod(w)
+
+
+def _b16_backward(f):
+    def w(ctx, *a):
+        with _b16_products(ctx.b16):
+            return f(ctx, *a)
+    return staticmethod(w)
+
+
 class _EmbedGru(torch.autograd.Function):
     """nn.Embedding + ImprovedRnn(nn.GRU bidirectional) (src/model.py:262-264, 12-21).  ``split`` > 0: the batch is two
     review tensors of ``split`` sequences each run in one launch (UMPR._pair); their outputs come back as two tensors
     (views of one buffer) and their gradients are joined by one concatenation instead of autograd's slice bookkeeping."""
 
-    @staticmethod
+    @_b16_forward
     def forward(ctx, ids, lengths, order, emb, split, *w):
         N, L = ids.shape
         E = emb.shape[1]
@@ -90,7 +125,7 @@ class _EmbedGru(torch.autograd.Function):
             return out[:split], out[split:]
         return out
 
-    @staticmethod
+    @_b16_backward
     def backward(ctx, *douts):
         ids, lengths, order, emb, whh_f, whh_r, saved = ctx.saved_tensors
         out = ctx.out
@@ -117,7 +152,7 @@ class _EmbedGru(torch.autograd.Function):
 class _ReviewHead(torch.autograd.Function):
     """R-Net co-attention + S-Net(u) + S-Net(i) + textual matching (src/model.py:50-55, 71-81, 162-168)."""
 
-    @staticmethod
+    @_b16_forward
     def forward(ctx, gru_u, gru_i, S, L, M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i, bf16=False):
         B, SL, _ = gru_u.shape
         dev = gru_u.device
@@ -149,7 +184,7 @@ class _ReviewHead(torch.autograd.Function):
                               rowmax, argrow, repr_u, repr_i, out, *sn)
         return out
 
-    @staticmethod
+    @_b16_backward
     def backward(ctx, d_out):
         (gru_u, gru_i, M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i, T, soft_u, soft_i, colmax, argcol, rowmax, argrow, repr_u,
          repr_i, out, U_u, P_u, wsum_u, sa_u, U_i, P_i, wsum_i, sa_i) = ctx.saved_tensors
@@ -185,7 +220,7 @@ class _ReviewHead(torch.autograd.Function):
 class _Control(torch.autograd.Function):
     """C-Net heads on (ui, user, item) + control S-Net + SS-Net gate (src/model.py:118-125, 179-198)."""
 
-    @staticmethod
+    @_b16_forward
     def forward(ctx, g_ui, g_u, g_i, dims, thr, Wc, bc, Wl, bl, Ms, Ws, ssW, ssb):
         B, S_ui, L_ui, S, L = dims
         KC, _, KS = Wc.shape
@@ -222,7 +257,7 @@ class _Control(torch.autograd.Function):
         ctx.save_for_backward(g_ui, g_u, g_i, Wc, Wl, Ms, Ws, ssW, c_out, U, P, wsum, sa, senti, vs, *saved)
         return finals[1], finals[2], pp, pn
 
-    @staticmethod
+    @_b16_backward
     def backward(ctx, d_cu, d_ci, d_pp, d_pn):
         (g_ui, g_u, g_i, Wc, Wl, Ms, Ws, ssW, c_out, U, P, wsum, sa, senti, vs, *saved) = ctx.saved_tensors
         B, S_ui, L_ui, S, L = ctx.dims
@@ -689,6 +724,13 @@ class UMPR(nn.Module):
                               cn.s_net.Ws, cn.ss_net.linear[0].weight, cn.ss_net.linear[0].bias)
 
     def forward(self, user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels):
+        _MODE["b16"] = self.compute_dtype == "bf16" and _TEXT_BF16
+        try:
+            return self._forward(user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels)
+        finally:
+            _MODE["b16"] = False
+
+    def _forward(self, user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels):
         device = self.embedding.weight.device
         if device.type != "cuda":
             raise RuntimeError("umpr_amd.UMPR runs on an MI355X only (no CPU fallback): move the module to a cuda device")
