@@ -44,11 +44,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   constexpr int LDA = LA::LD, LDB = LB::LD;
   constexpr int WTM = BM / 2, WTN = BN / 2;  // 2x2 waves
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int L16 = LA::LDB16;
   __shared__ __attribute__((aligned(16))) float As[B16 ? 1 : 2][B16 ? 4 : BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[B16 ? 1 : 2][B16 ? 4 : BK * LDB];
-  __shared__ __attribute__((aligned(16))) __bf16 Ah[B16 ? 2 : 1][B16 ? BM * L16 : 8];
-  __shared__ __attribute__((aligned(16))) __bf16 Bh[B16 ? 2 : 1][B16 ? BN * L16 : 8];
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[B16 ? 2 : 1][B16 ? LA::B16_ELEMS : 8];
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[B16 ? 2 : 1][B16 ? LB::B16_ELEMS : 8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -99,9 +98,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     if constexpr (B16) {
       gemm_bf16x8 ah[TM], bh[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const gemm_bf16x8*>(&Ah[cur][(wm * WTM + i * 32 + l31) * L16 + 8 * kh]);
+      for (int i = 0; i < TM; ++i) ah[i] = LA::frag_b16(Ah[cur], wm * WTM + i * 32, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const gemm_bf16x8*>(&Bh[cur][(wn * WTN + j * 32 + l31) * L16 + 8 * kh]);
+      for (int j = 0; j < TN; ++j) bh[j] = LB::frag_b16(Bh[cur], wn * WTN + j * 32, lane);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll

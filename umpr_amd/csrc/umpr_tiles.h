@@ -77,7 +77,12 @@ struct TileRegs {
 
   // bf16 stage image for v_mfma_f32_32x32x16_bf16: S[row][LDB16] bf16, row = the tile's m / n index, 16 k per row (32 B)
   // padded to 48 B - 16 lanes x ds_read_b128 at a 48-B stride touch 64 distinct banks
+  // An operand whose global rows are k (KCONTIG = false) keeps that order in LDS - S[k][LDT16] bf16, one 8-B store per float4
+  // (the row-major image would need four scattered 2-B stores that land 16-way on four banks) - and its MFMA fragments come
+  // from ds_read_b64_tr_b16.  Row pitch 320 B: the 4 rows x 2 column groups a half-wave reads fall into 64 distinct banks.
   static constexpr int LDB16 = 24;
+  static constexpr int LDT16 = 160;
+  static constexpr int B16_ELEMS = KCONTIG ? TILE * LDB16 : BK * LDT16;
   __device__ __forceinline__ void store_b16(__bf16* __restrict__ S, int tid) const {
     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -93,11 +98,29 @@ struct TileRegs {
       } else {
         constexpr int QPR = TILE / 4;
         const int k = e / QPR, q = e % QPR;
-        S[(4 * q + 0) * LDB16 + k] = (__bf16)val.x;
-        S[(4 * q + 1) * LDB16 + k] = (__bf16)val.y;
-        S[(4 * q + 2) * LDB16 + k] = (__bf16)val.z;
-        S[(4 * q + 3) * LDB16 + k] = (__bf16)val.w;
+        bf16x4_ o;
+        o[0] = (__bf16)val.x; o[1] = (__bf16)val.y; o[2] = (__bf16)val.z; o[3] = (__bf16)val.w;
+        *reinterpret_cast<bf16x4_*>(&S[k * LDT16 + 4 * q]) = o;
       }
+    }
+  }
+
+  // MFMA fragment (8 consecutive k of row `row0 + (lane & 31)`, k-half lane >> 5) of the stage image written by store_b16
+  typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x4t_ __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ bf16x8_ frag_b16(const __bf16* __restrict__ S, int row0, int lane) {
+    if (KCONTIG) {
+      return *reinterpret_cast<const bf16x8_*>(&S[(row0 + (lane & 31)) * LDB16 + 8 * (lane >> 5)]);
+    } else {
+      const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+      const __bf16* a = &S[(8 * (g >> 1) + q4) * LDT16 + row0 + 16 * (g & 1) + 4 * p4];
+      typedef __attribute__((address_space(3))) void* lds_void_t;
+      const bf16x4t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4t_ __attribute__((address_space(3)))*)(lds_void_t)(a));
+      const bf16x4t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4t_ __attribute__((address_space(3)))*)(lds_void_t)(a + 4 * LDT16));
+      bf16x8_ r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
+      return r;
     }
   }
 };
