@@ -7,9 +7,12 @@ constexpr int KFLUSH = 8;  // k-tiles per MFMA accumulation chain before folding
 
 // One operand tile (TILE x BK) held in registers between the global load and the LDS store.
 // KCONTIG: global rows are the tile's m/n index, contiguous along k.  else: global rows are k, contiguous along m/n.
-template <int TILE, bool KCONTIG>
+// BKT: k-depth of the stage (16 everywhere except the bf16 GEMM, whose stages are bound by the latency of their global loads:
+// 32 there halves the number of round trips).
+template <int TILE, bool KCONTIG, int BKT = BK>
 struct TileRegs {
-  static constexpr int NV = TILE * BK / 4 / 256;
+  static constexpr int NV = TILE * BKT / 4 / 256;
+  static constexpr int KQ = BKT / 4;                   // float4 per k-contiguous row of the stage
   static constexpr int LD = KCONTIG ? TILE + 2 : TILE + 4;
   float4 r[NV];
 
@@ -28,7 +31,7 @@ struct TileRegs {
       int o0, o1, o2, o3;
       const float* p;
       if (KCONTIG) {
-        const int mn = e >> 2, kq = e & 3;
+        const int mn = e / KQ, kq = e % KQ;
         const int gm = mn0 + mn, gk = k0 + 4 * kq;
         long row = gm < MN ? (long)gm : -1;
         if (gather) row = gather[gm < MN ? gm : 0] | (gm < MN ? 0L : -1L);
@@ -62,7 +65,7 @@ struct TileRegs {
       const unsigned m = okmask >> (4 * v);
       const float4 val = make_float4((m & 1) ? r[v].x : 0.f, (m & 2) ? r[v].y : 0.f, (m & 4) ? r[v].z : 0.f, (m & 8) ? r[v].w : 0.f);
       if (KCONTIG) {
-        const int mn = e >> 2, kq = e & 3;
+        const int mn = e / KQ, kq = e % KQ;
         S[(4 * kq + 0) * LD + mn] = val.x;
         S[(4 * kq + 1) * LD + mn] = val.y;
         S[(4 * kq + 2) * LD + mn] = val.z;
@@ -80,9 +83,9 @@ struct TileRegs {
   // An operand whose global rows are k (KCONTIG = false) keeps that order in LDS - S[k][LDT16] bf16, one 8-B store per float4
   // (the row-major image would need four scattered 2-B stores that land 16-way on four banks) - and its MFMA fragments come
   // from ds_read_b64_tr_b16.  Row pitch 320 B: the 4 rows x 2 column groups a half-wave reads fall into 64 distinct banks.
-  static constexpr int LDB16 = 24;
+  static constexpr int LDB16 = BKT + 8;               // 48-B rows for 16 k, 80-B rows for 32 k: both conflict-free for b128 reads
   static constexpr int LDT16 = 160;
-  static constexpr int B16_ELEMS = KCONTIG ? TILE * LDB16 : BK * LDT16;
+  static constexpr int B16_ELEMS = KCONTIG ? TILE * LDB16 : BKT * LDT16;
   __device__ __forceinline__ void store_b16(__bf16* __restrict__ S, int tid) const {
     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -91,7 +94,7 @@ struct TileRegs {
       const unsigned m = okmask >> (4 * v);
       const float4 val = make_float4((m & 1) ? r[v].x : 0.f, (m & 2) ? r[v].y : 0.f, (m & 4) ? r[v].z : 0.f, (m & 8) ? r[v].w : 0.f);
       if (KCONTIG) {
-        const int mn = e >> 2, kq = e & 3;
+        const int mn = e / KQ, kq = e % KQ;
         bf16x4_ o;
         o[0] = (__bf16)val.x; o[1] = (__bf16)val.y; o[2] = (__bf16)val.z; o[3] = (__bf16)val.w;
         *reinterpret_cast<bf16x4_*>(&S[mn * LDB16 + 4 * kq]) = o;
@@ -108,12 +111,12 @@ struct TileRegs {
   // MFMA fragment (8 consecutive k of row `row0 + (lane & 31)`, k-half lane >> 5) of the stage image written by store_b16
   typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
   typedef __bf16 bf16x4t_ __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ bf16x8_ frag_b16(const __bf16* __restrict__ S, int row0, int lane) {
+  static __device__ __forceinline__ bf16x8_ frag_b16(const __bf16* __restrict__ S, int row0, int lane, int ks = 0) {
     if (KCONTIG) {
-      return *reinterpret_cast<const bf16x8_*>(&S[(row0 + (lane & 31)) * LDB16 + 8 * (lane >> 5)]);
+      return *reinterpret_cast<const bf16x8_*>(&S[(row0 + (lane & 31)) * LDB16 + 16 * ks + 8 * (lane >> 5)]);
     } else {
       const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-      const __bf16* a = &S[(8 * (g >> 1) + q4) * LDT16 + row0 + 16 * (g & 1) + 4 * p4];
+      const __bf16* a = &S[(16 * ks + 8 * (g >> 1) + q4) * LDT16 + row0 + 16 * (g & 1) + 4 * p4];
       typedef __attribute__((address_space(3))) void* lds_void_t;
       const bf16x4t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4t_ __attribute__((address_space(3)))*)(lds_void_t)(a));
       const bf16x4t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4t_ __attribute__((address_space(3)))*)(lds_void_t)(a + 4 * LDT16));
