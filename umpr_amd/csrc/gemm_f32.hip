@@ -30,6 +30,7 @@ struct GemmParams {
   int act; int accumulate; float alpha;
   int split_k; int k_per_split; float* ws;
   int vecA, vecB;
+  int waL, waD, waP, wbL, wbD, wbP;   // sliding-window operands (UmprGemm::winA / winB), L == 0: off
 };
 
 // B16 (mixed-precision mode, text path): operands stay fp32 in memory and are rounded to bf16 when a stage is written to
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   LB rb;
   const int nt = (kend - kbeg + BKS - 1) / BKS;
   if (nt > 0) {
-    ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg, kend, p.vecA, tid);
-    rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg, kend, p.vecB, tid);
+    ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg, kend, p.vecA, tid, p.waL, p.waD, p.waP);
+    rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg, kend, p.vecB, tid, p.wbL, p.wbD, p.wbP);
     if (B16) { ra.store_b16(Ah[0], tid); rb.store_b16(Bh[0], tid); }
     else { ra.store(As[0], tid); rb.store(Bs[0], tid); }
   }
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   for (int t = t0; t < t1; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt) {
-      ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg + (t + 1) * BKS, kend, p.vecA, tid);
-      rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg + (t + 1) * BKS, kend, p.vecB, tid);
+      ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg + (t + 1) * BKS, kend, p.vecA, tid, p.waL, p.waD, p.waP);
+      rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg + (t + 1) * BKS, kend, p.vecB, tid, p.wbL, p.wbD, p.wbP);
     }
     if constexpr (B16) {
 #pragma unroll
@@ -226,6 +227,10 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   p.gatherA = g.gatherA; p.gatherB = g.gatherB;
   p.bias = g.bias; p.bias_mode = g.bias ? g.bias_mode : 0;
   p.act = g.act; p.accumulate = g.accumulate ? 1 : 0; p.alpha = g.alpha;
+  UMPR_REQUIRE(!(g.winA_L && (g.transA || g.gatherA || (g.winA_D & 3))) && !(g.winB_L && (g.transB || g.gatherB || (g.winB_D & 3))),
+               "gemm: a sliding-window operand must be row-major, ungathered, with a row length that is a multiple of 4");
+  UMPR_REQUIRE((!g.winA_L || g.lda == g.winA_D) && (!g.winB_L || g.ldb == g.winB_D), "gemm: window operand with a padded row pitch");
+  p.waL = g.winA_L; p.waD = g.winA_D; p.waP = g.winA_pad; p.wbL = g.winB_L; p.wbD = g.winB_D; p.wbP = g.winB_pad;
   // float4 staging needs 16-B aligned rows and a contiguous extent that is a multiple of 4 (no partial vectors)
   p.vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && (((g.transA ? g.M : g.K) & 3) == 0);
   p.vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && (((g.transB ? g.K : g.N) & 3) == 0);

@@ -140,34 +140,19 @@ __global__ __launch_bounds__(256) void snet_pool_bwd_kernel(SnetBwdParams p, lon
 }
 
 // -------------------------------------------------------------------------------------------------- C-Net
-// Xcol[r][c*3+dk] = X[r+dk-1][c] inside the sentence, else 0      (kernel_size 3, padding 1)
-__global__ void im2col1d_kernel(const float* __restrict__ X, float* __restrict__ Xcol, long R, int L, int C, int KS) {
-  const long total = R * C * KS;
-  const int pad = (KS - 1) / 2;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int dk = (int)(i % KS);
-    const long q = i / KS;
-    const int c = (int)(q % C);
-    const long r = q / C;
-    const int l = (int)(r % L) + dk - pad;
-    Xcol[i] = (l >= 0 && l < L) ? X[(r + dk - pad) * C + c] : 0.f;
-  }
-}
-// dX[r][c] = sum_dk dXcol[r-dk+1][c*3+dk]
-__global__ void col2im1d_kernel(const float* __restrict__ dXcol, float* __restrict__ dX, long R, int L, int C, int KS,
-                                int accumulate) {
-  const long total = R * C;
-  const int pad = (KS - 1) / 2;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const long r = i / C;
-    const int l = (int)(r % L);
-    float v = 0.f;
-    for (int dk = 0; dk < KS; ++dk) {
-      const int ls = l - dk + pad;
-      if (ls >= 0 && ls < L) v += dXcol[((r - dk + pad) * C + c) * KS + dk];
-    }
-    dX[i] = accumulate ? dX[i] + v : v;
+// Conv1d as a GEMM over a sliding-window view of X (UmprGemm::winA / winB): no im2col / col2im buffers.  The window's
+// column order is (tap j, channel c), the parameter's is (c, j): three small re-orderings of the [KC][D][KS] weight.
+//   mode 0: Wp [kc][j*D + c]   = Wc[kc][c*KS + j]                 forward:  Y = win(X) Wp^T
+//   mode 1: Wq [j*KC + kc][c]  = Wc[kc][c*KS + (KS-1-j)]          backward: dX = win(dY) Wq
+//   mode 2: dWc[kc][c*KS + j] (+)= dWp[kc][j*D + c]               backward: dWp = dY^T win(X)
+__global__ void cnet_weight_order_kernel(const float* __restrict__ src, float* __restrict__ dst, int KC, int Dc, int KS,
+                                         int mode, int accumulate) {
+  const int total = KC * Dc * KS;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i % KS, c = (i / KS) % Dc, kc = i / (KS * Dc);   // i = index into Wc / dWc
+    if (mode == 0) dst[(long)kc * Dc * KS + j * Dc + c] = src[i];
+    else if (mode == 1) dst[((long)(KS - 1 - j) * KC + kc) * Dc + c] = src[i];
+    else { const float v = src[(long)kc * Dc * KS + j * Dc + c]; dst[i] = accumulate ? dst[i] + v : v; }
   }
 }
 
@@ -803,18 +788,21 @@ int umpr_snet_bwd_impl(const float* X, const float* Ms, const float* Ws, const f
 }
 
 // ---- C-Net head ------------------------------------------------------------------------------------------------
-size_t umpr_cnet_fwd_ws_bytes(int B, int S, int L, int KS) { return (size_t)B * S * L * D * KS * sizeof(float); }
+// forward scratch: the window-ordered weight [KC][KS*D] (KC <= 512)
+size_t umpr_cnet_fwd_ws_bytes(int B, int S, int L, int KS) { (void)B; (void)S; (void)L; return (size_t)512 * D * KS * sizeof(float); }
 
 int umpr_cnet_head_fwd_impl(const float* X, const float* Wc, const float* bc, const float* Wl, const float* bl,
                             float thr, int B, int S, int L, int KC, int KS, int V, float* Y, float* cmax, int* argl,
                             float* sp, float* view_p, float* final_, float* ws, size_t ws_bytes, hipStream_t s) {
   UMPR_REQUIRE(ws_bytes >= umpr_cnet_fwd_ws_bytes(B, S, L, KS), "cnet: workspace too small");
   const long R = (long)B * S * L;
-  float* Xcol = ws;
-  im2col1d_kernel<<<nblocks(R * D * KS), 256, 0, s>>>(X, Xcol, R, L, D, KS);
-  UMPR_LAUNCH_CHECK("im2col1d");
-  UmprGemm g;
-  g.A = Xcol; g.lda = D * KS; g.B = Wc; g.ldb = D * KS; g.transB = true; g.C = Y; g.ldc = KC; g.M = (int)R; g.N = KC;
+  UMPR_REQUIRE((KS & 1) == 1 && KC <= 512, "cnet: even kernel size %d or more than 512 filters (%d)", KS, KC);
+  float* Wp = ws;                                        // [KC][KS*D] in window order
+  cnet_weight_order_kernel<<<nblocks((long)KC * D * KS), 256, 0, s>>>(Wc, Wp, KC, D, KS, 0, 0);
+  UMPR_LAUNCH_CHECK("cnet_weight_order");
+  UmprGemm g;   // Y = relu(win(X) Wp^T + bc): X read in place through the sliding window
+  g.A = X; g.lda = D; g.winA_L = L; g.winA_D = D; g.winA_pad = (KS - 1) / 2;
+  g.B = Wp; g.ldb = D * KS; g.transB = true; g.C = Y; g.ldc = KC; g.M = (int)R; g.N = KC;
   g.K = D * KS; g.bias = bc; g.bias_mode = 1; g.act = UMPR_ACT_RELU;
   if (int rc = umpr_gemm(g, s)) return rc;
   CnetHeadFwdParams p{Y, Wl, bl, thr, cmax, argl, sp, view_p, final_, S, L, KC, V};
@@ -828,7 +816,8 @@ int umpr_cnet_head_fwd_impl(const float* X, const float* Wc, const float* bc, co
 
 size_t umpr_cnet_bwd_ws_bytes(int B, int S, int L, int KC, int KS, int V) {
   const size_t R = (size_t)B * S * L;
-  return (R * KC + 2 * R * D * KS + (size_t)B * V * KC + (size_t)B * V + (size_t)cdiv(R, 256) * KC +
+  // dY + dWp + Wq (window-ordered weight gradient / transposed weight) + head partials + split-K slab
+  return (R * KC + 2 * (size_t)KC * D * KS + (size_t)B * V * KC + (size_t)B * V + (size_t)cdiv(R, 256) * KC +
           (size_t)512 * KC * D * KS) * sizeof(float);
 }
 
@@ -840,9 +829,9 @@ int umpr_cnet_head_bwd_impl(const float* X, const float* Wc, const float* Wl, co
   const long R = (long)B * S * L;
   const int CK = D * KS;
   float* dY = ws;
-  float* Xcol = dY + R * KC;
-  float* dXcol = Xcol + R * CK;
-  float* dWl_part = dXcol + R * CK;
+  float* dWp = dY + R * KC;                              // [KC][CK] in window order
+  float* Wq = dWp + (size_t)KC * CK;                     // [KS*KC][D]
+  float* dWl_part = Wq + (size_t)KC * CK;
   float* dbl_part = dWl_part + (size_t)B * V * KC;
   float* cs = dbl_part + (size_t)B * V;
   float* slab = cs + (size_t)cdiv(R, 256) * KC;
@@ -854,17 +843,20 @@ int umpr_cnet_head_bwd_impl(const float* X, const float* Wc, const float* Wl, co
   colsum_stage2_kernel<<<cdiv(V, 64), 256, 0, s>>>(dbl_part, B, V, dbl, accumulate_w);
   UMPR_LAUNCH_CHECK("cnet_dWl");
   if (int rc = umpr_colsum(dY, R, KC, KC, dbc, accumulate_w, cs, (size_t)cdiv(R, 256) * KC * sizeof(float), s)) return rc;
-  im2col1d_kernel<<<nblocks(R * CK), 256, 0, s>>>(X, Xcol, R, L, D, KS);
-  UMPR_LAUNCH_CHECK("im2col1d");
-  UmprGemm h;  // dWc[KC][CK] = dY^T Xcol
-  h.A = dY; h.lda = KC; h.transA = true; h.B = Xcol; h.ldb = CK; h.C = dWc; h.ldc = CK; h.M = KC; h.N = CK; h.K = (int)R;
-  h.split_k = 0; h.ws = slab; h.ws_bytes = (size_t)512 * KC * CK * sizeof(float); h.accumulate = accumulate_w != 0;
+  UMPR_REQUIRE((KS & 1) == 1 && (KC & 3) == 0, "cnet_bwd: kernel size %d / %d filters", KS, KC);
+  const int pad = (KS - 1) / 2;
+  UmprGemm h;  // dWp[KC][CK] = dY^T win(X)
+  h.A = dY; h.lda = KC; h.transA = true; h.B = X; h.ldb = D; h.winB_L = L; h.winB_D = D; h.winB_pad = pad;
+  h.C = dWp; h.ldc = CK; h.M = KC; h.N = CK; h.K = (int)R;
+  h.split_k = 0; h.ws = slab; h.ws_bytes = (size_t)512 * KC * CK * sizeof(float);
   if (int rc = umpr_gemm(h, s)) return rc;
-  UmprGemm g;  // dXcol = dY Wc
-  g.A = dY; g.lda = KC; g.B = Wc; g.ldb = CK; g.C = dXcol; g.ldc = CK; g.M = (int)R; g.N = CK; g.K = KC;
+  cnet_weight_order_kernel<<<nblocks((long)KC * CK), 256, 0, s>>>(dWp, dWc, KC, D, KS, 2, accumulate_w);
+  cnet_weight_order_kernel<<<nblocks((long)KC * CK), 256, 0, s>>>(Wc, Wq, KC, D, KS, 1, 0);
+  UMPR_LAUNCH_CHECK("cnet_weight_order");
+  UmprGemm g;  // dX (+)= win(dY) Wq: the transposed convolution, again through the window
+  g.A = dY; g.lda = KC; g.winA_L = L; g.winA_D = KC; g.winA_pad = pad;
+  g.B = Wq; g.ldb = D; g.C = dX; g.ldc = D; g.M = (int)R; g.N = D; g.K = KS * KC; g.accumulate = accumulate_dX != 0;
   if (int rc = umpr_gemm(g, s)) return rc;
-  col2im1d_kernel<<<nblocks(R * D), 256, 0, s>>>(dXcol, dX, R, L, D, KS, accumulate_dX);
-  UMPR_LAUNCH_CHECK("col2im1d");
   return 0;
 }
 

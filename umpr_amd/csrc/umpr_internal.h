@@ -14,6 +14,11 @@ struct UmprGemm {
   int act = 0; bool accumulate = false; float alpha = 1.0f;
   int split_k = 1;                   // 0 = auto (needs ws)
   float* ws = nullptr; size_t ws_bytes = 0;
+  // Sliding-window operand (1-D convolution as a GEMM without im2col): the operand is a matrix X [rows][winD] of
+  // sentences of winL rows, and its logical element (row r, column j*winD + c) is X[r + j - winPad][c], zero where
+  // (r % winL) + j - winPad leaves the sentence.  winA: A [M][KS*winD] (!transA);  winB: B [K][KS*winD] (!transB).
+  int winA_L = 0, winA_D = 1, winA_pad = 0;
+  int winB_L = 0, winB_D = 1, winB_pad = 0;
 };
 void umpr_gemm_set_b16(int on);
 int umpr_gemm(const UmprGemm& g, hipStream_t stream);

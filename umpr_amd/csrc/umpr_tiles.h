@@ -22,8 +22,12 @@ struct TileRegs {
   // per load: the loads then complete one L2 round trip after the other (rocprofv3: SQ_WAIT_ANY was 43% of the wave
   // lifetime).  vec_ok (wave-uniform) promises 16-B alignment and extents that are multiples of 4.
   unsigned okmask;
+  // winL > 0: sliding-window operand (UmprGemm::winA / winB) - the operand's row index (mn when KCONTIG, k otherwise) is a
+  // sentence position, element (row, col) lives at base[(row - winPad) * ld + col] and exists iff
+  // 0 <= row % winL + col / winD - winPad < winL.  A float4 never straddles a window step (winD % 4 == 0).
   __device__ __forceinline__ void load(const float* __restrict__ base, long ld, const int64_t* __restrict__ gather,
-                                       int mn0, int MN, int k0, int kend, int vec_ok, int tid) {
+                                       int mn0, int MN, int k0, int kend, int vec_ok, int tid, int winL = 0, int winD = 1,
+                                       int winPad = 0) {
     okmask = 0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -35,7 +39,8 @@ struct TileRegs {
         const int gm = mn0 + mn, gk = k0 + 4 * kq;
         long row = gm < MN ? (long)gm : -1;
         if (gather) row = gather[gm < MN ? gm : 0] | (gm < MN ? 0L : -1L);
-        const bool rv = row >= 0;
+        bool rv = row >= 0;
+        if (winL) { const int tpos = gm % winL + gk / winD - winPad; rv = rv && tpos >= 0 && tpos < winL; row -= winPad; }
         p = base + (rv ? row * ld + gk : 0);
         o0 = rv && gk < kend; o1 = rv && gk + 1 < kend; o2 = rv && gk + 2 < kend; o3 = rv && gk + 3 < kend;
       } else {
@@ -44,7 +49,8 @@ struct TileRegs {
         const int gk = k0 + k, gm = mn0 + 4 * q;
         long row = gk < kend ? (long)gk : -1;
         if (gather) row = gather[gk < kend ? gk : 0] | (gk < kend ? 0L : -1L);
-        const bool rv = row >= 0;
+        bool rv = row >= 0;
+        if (winL) { const int tpos = gk % winL + gm / winD - winPad; rv = rv && tpos >= 0 && tpos < winL; row -= winPad; }
         p = base + (rv ? row * ld + gm : 0);
         o0 = rv && gm < MN; o1 = rv && gm + 1 < MN; o2 = rv && gm + 2 < MN; o3 = rv && gm + 3 < MN;
       }
