@@ -252,7 +252,8 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
     // batch-sized M (the VGG classifier at 64 images): the kernel streams a weight matrix once and is bound by memory
     // latency, not by the MFMA pipe or HBM - more workgroups in flight (3 fit a CU) hide it
     static const int small_m_target = [] { const char* v = getenv("UMPR_GEMM_SMALL_M_WGS"); return v ? atoi(v) : 512; }();
-    const int target = g.M <= 64 ? small_m_target : 512;
+    static const int b16_target = [] { const char* v = getenv("UMPR_GEMM_B16_WGS"); return v ? atoi(v) : 512; }();
+    const int target = t_gemm_b16 ? b16_target : (g.M <= 64 ? small_m_target : 512);
     if (tiles < target / 2 && g.K >= 512) {
       split = (int)((target + tiles - 1) / tiles);
       const int maxs = g.K / 128;
