@@ -1066,6 +1066,47 @@ __global__ void wgrad_reduce_linear_kernel(const float* __restrict__ slab, const
   }
 }
 
+// The same for layers with many splits (the 64- and 128-channel layers: one or two output tiles, so 128-256 splits): a
+// thread of the kernel above walks all of them one dependent load after the other (200 us for the 36 864 weights of
+// conv1_2, at the very end of the backward pass).  Here 1024 threads = 64 float4 columns x 16 split groups; a group sums the
+// splits q = g, g + 16, ... in order, the groups are combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void wgrad_reduce_wide_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                                 int splits, long per, int Cout, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int accumulate) {
+  __shared__ float4 red[16][64];
+  const long nv = per / 4;
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + c;
+  const long nvb = nv + (bslab ? (Cout + 3) / 4 : 0);     // bias columns follow, four channels per "column"
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < nv) {
+    const float4* s4 = reinterpret_cast<const float4*>(slab);
+    for (int q = g; q < splits; q += 16) { const float4 u = s4[(long)q * nv + i]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+  } else if (i < nvb) {
+    const int co = (int)(i - nv) * 4;
+    for (int q = g; q < splits; q += 16) {
+      const float* b = bslab + (long)q * Cout + co;
+      a.x += b[0]; if (co + 1 < Cout) a.y += b[1]; if (co + 2 < Cout) a.z += b[2]; if (co + 3 < Cout) a.w += b[3];
+    }
+  }
+  red[g][c] = a;
+  __syncthreads();
+  if (g == 0 && i < nvb) {
+    float4 r = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 u = red[k][c]; r.x += u.x; r.y += u.y; r.z += u.z; r.w += u.w; }
+    if (i < nv) {
+      float4* d4 = reinterpret_cast<float4*>(dw);
+      if (accumulate) { const float4 o = d4[i]; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+      d4[i] = r;
+    } else {
+      const int co = (int)(i - nv) * 4;
+      const float v[4] = {r.x, r.y, r.z, r.w};
+      for (int e = 0; e < 4 && co + e < Cout; ++e) db[co + e] = accumulate ? db[co + e] + v[e] : v[e];
+    }
+  }
+}
+
 // bias gradient partial sums: bslab[chunk][co] = sum over the chunk's pixels of dY[P][co]
 __global__ __launch_bounds__(256) void bias_grad_bf16_kernel(const bf16_t* __restrict__ dy, long dps, long ptot,
                                                             int Cout, int nchunk, float* __restrict__ bslab) {
@@ -1612,9 +1653,15 @@ int umpr_wgrad_bf16_run(const void* dy, const void* x, float* dw, float* db, con
   }
   UMPR_LAUNCH_CHECK("wgrad_bf16");
   const long per = (long)9 * Cout * Cin;
-  wgrad_reduce_linear_kernel<<<grid_for(per / 4 + Cout, 2048), 256, 0, s>>>(ws, db ? p.bslab : nullptr, q.splits, per, Cout,
-                                                                            dw, db, accumulate);
-  UMPR_LAUNCH_CHECK("wgrad_reduce_linear");
+  if (q.splits >= 32) {
+    const long cols = per / 4 + (db ? (Cout + 3) / 4 : 0);
+    wgrad_reduce_wide_kernel<<<(unsigned)((cols + 63) / 64), 1024, 0, s>>>(ws, db ? p.bslab : nullptr, q.splits, per, Cout, dw,
+                                                                          db, accumulate);
+  } else {
+    wgrad_reduce_linear_kernel<<<grid_for(per / 4 + Cout, 2048), 256, 0, s>>>(ws, db ? p.bslab : nullptr, q.splits, per, Cout,
+                                                                              dw, db, accumulate);
+  }
+  UMPR_LAUNCH_CHECK("wgrad_reduce");
   return 0;
 }
 

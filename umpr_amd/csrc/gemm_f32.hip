@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   LA ra;
   LB rb;
   const int nt = (kend - kbeg + BKS - 1) / BKS;
+  ra.cache_rows(p.gatherA, m0, p.M, tid);
   if (nt > 0) {
     ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg, kend, p.vecA, tid, p.waL, p.waD, p.waP);
     rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg, kend, p.vecB, tid, p.wbL, p.wbD, p.wbP);

@@ -366,14 +366,16 @@ __global__ __launch_bounds__(64) void gate_bwd_kernel(GateBwdParams p) {
 // -------------------------------------------------------------------------------------------------- head
 using HeadParams = UmprHead;
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
-  __shared__ float red[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// pos/neg view embeddings and image embeddings: one wave per dot product of length F, over the whole grid (the single
+// workgroup of head_fwd_kernel walked the 2V + BV products four at a time: 140 us on the step's critical path)
+__global__ __launch_bounds__(256) void head_emb_kernel(HeadParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int B = p.B, V = p.V;
-  if (V > 0) {
-    // pos/neg view embeddings and image embeddings: one wave per dot product of length F
-    const int ndot = 2 * V + B * V;
-    for (int d = wave; d < ndot; d += 4) {
+  const int ndot = 2 * V + B * V;
+  {
+    {
+      const int d = blockIdx.x * 4 + wave;
+      if (d >= ndot) return;
       float a = 0.f;
       if (d < 2 * V) {
         const float* src = (d < V ? p.pos_v + (long)d * p.F : p.neg_v + (long)(d - V) * p.F);
@@ -391,7 +393,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
         if (d < 2 * V) p.posneg_emb[d] = a; else p.img_emb[d - 2 * V] = a;
       }
     }
-    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int B = p.B, V = p.V;
+  if (V > 0) {   // posneg_emb / img_emb come from head_emb_kernel
     for (int i = tid; i < B * V; i += 256) {
       const int v = i % V;
       const float ie = p.img_emb[i];
@@ -440,6 +449,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
   const int B = p.B, V = p.V, FW = D + 2 * V;
   float* dz = sm; float* dimg = sm + B; float* ddps = dimg + B * V; float* ddns = ddps + B * V;
   float* dpos = ddns + B * V; float* dneg = dpos + V;
+  // gridDim.x workgroups: every one repeats the O(B V) prefix in its own LDS, workgroup 0 alone writes the small outputs,
+  // and the 1000-wide loop over the VGG features (64 dependent iterations per element) is sliced over the workgroups
+  const bool first = blockIdx.x == 0;
   const float gl = p.d_loss[0];
   for (int b = tid; b < B; b += 256) {
     float g = gl * 2.f * (p.pred[b] - p.labels[b]) / (float)B;
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
   }
   __syncthreads();
   // fusion layer
-  for (int i = tid; i < FW; i += 256) {
+  for (int i = tid; first && i < FW; i += 256) {
     float a = 0.f;
     for (int b = 0; b < B; ++b) {
       float f;
@@ -463,23 +475,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
     float a = 0.f;
     for (int b = tid; b < B; b += 256) a += dz[b];
     a = block_sum4(a, red);
-    if (tid == 0) p.d_fb[0] = a;
+    if (first && tid == 0) p.d_fb[0] = a;
   }
-  for (int i = tid; i < B * D; i += 256) p.d_rr[i] = dz[i / D] * p.fw[i % D];
+  for (int i = tid; first && i < B * D; i += 256) p.d_rr[i] = dz[i / D] * p.fw[i % D];
   if (V == 0) return;
   const float sv = gl * p.rate / (float)(V * V);
   for (int i = tid; i < B * V; i += 256) {
     const int b = i / V, v = i % V;
     const float cu = p.c_u[i], ci = p.c_i[i], pm = p.pos_match[i], nm = p.neg_match[i];
     const float dfp = dz[b] * p.fw[D + v], dfn = dz[b] * p.fw[D + V + v];
-    p.d_cu[i] = dfp * ci * (1.f - pm) + dfn * ci * (1.f - nm);
-    p.d_ci[i] = dfp * cu * (1.f - pm) + dfn * cu * (1.f - nm);
+    if (first) {
+      p.d_cu[i] = dfp * ci * (1.f - pm) + dfn * ci * (1.f - nm);
+      p.d_ci[i] = dfp * cu * (1.f - pm) + dfn * cu * (1.f - nm);
+    }
     float spm = 0.f, snm = 0.f, spp = 0.f, spn = 0.f;
     for (int q = 0; q < V; ++q) {
       spm += p.pos_match[b * V + q]; snm += p.neg_match[b * V + q];
       spp += p.pp[b * V + q]; spn += p.pn[b * V + q];
     }
-    p.d_pp[i] = sv * spm; p.d_pn[i] = sv * snm;
+    if (first) { p.d_pp[i] = sv * spm; p.d_pn[i] = sv * snm; }
     const float dpm = -dfp * cu * ci + sv * spp;
     const float dnm = -dfn * cu * ci + sv * spn;
     const float ie = p.img_emb[i];
@@ -497,7 +511,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
     dpos[v] = a; dneg[v] = c;
   }
   __syncthreads();
-  for (int i = tid; i < p.F; i += 256) {
+  for (int i = blockIdx.x * 256 + tid; i < p.F; i += gridDim.x * 256) {
     const float lwi = p.lw[i];
     float a = 0.f;
     for (int bv = 0; bv < B * V; ++bv) {
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
     for (int i = tid; i < B * V; i += 256) a += dimg[i];
     for (int v = tid; v < V; v += 256) a += dpos[v] + dneg[v];
     a = block_sum4(a, red);
-    if (tid == 0) p.d_lb[0] = a;
+    if (first && tid == 0) p.d_lb[0] = a;
   }
 }
 
@@ -886,11 +900,15 @@ int umpr_gate_bwd_impl(const float* sa, const float* w, const float* view_p, con
 // ---- head ------------------------------------------------------------------------------------------------------
 int umpr_head_launch(const UmprHead& p, int backward, hipStream_t s) {
   if (!backward) {
+    if (p.V > 0) {
+      head_emb_kernel<<<(2 * p.V + p.B * p.V + 3) / 4, 256, 0, s>>>(p);
+      UMPR_LAUNCH_CHECK("head_emb");
+    }
     head_fwd_kernel<<<1, 256, 0, s>>>(p);
     UMPR_LAUNCH_CHECK("head_fwd");
   } else {
     const size_t sh = ((size_t)p.B + 3 * (size_t)p.B * p.V + 2 * p.V) * sizeof(float);
-    head_bwd_kernel<<<1, 256, sh, s>>>(p);
+    head_bwd_kernel<<<p.V > 0 ? (p.F + 255) / 256 : 1, 256, sh, s>>>(p);
     UMPR_LAUNCH_CHECK("head_bwd");
   }
   return 0;

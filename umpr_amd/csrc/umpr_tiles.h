@@ -22,6 +22,19 @@ struct TileRegs {
   // per load: the loads then complete one L2 round trip after the other (rocprofv3: SQ_WAIT_ANY was 43% of the wave
   // lifetime).  vec_ok (wave-uniform) promises 16-B alignment and extents that are multiples of 4.
   unsigned okmask;
+  // gathered rows of a k-contiguous operand are the same for every k-stage: looked up once (rows_cached), not once per stage
+  // in front of the dependent data load (the embedding gather of the GRU input projection: two global round trips per stage)
+  long grow[NV];
+  bool rows_cached = false;
+  __device__ __forceinline__ void cache_rows(const int64_t* __restrict__ gather, int mn0, int MN, int tid) {
+    if (!KCONTIG || !gather) return;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int gm = mn0 + (tid + v * 256) / KQ;
+      grow[v] = gather[gm < MN ? gm : 0] | (gm < MN ? 0L : -1L);
+    }
+    rows_cached = true;
+  }
   // winL > 0: sliding-window operand (UmprGemm::winA / winB) - the operand's row index (mn when KCONTIG, k otherwise) is a
   // sentence position, element (row, col) lives at base[(row - winPad) * ld + col] and exists iff
   // 0 <= row % winL + col / winD - winPad < winL.  A float4 never straddles a window step (winD % 4 == 0).
@@ -38,7 +51,7 @@ struct TileRegs {
         const int mn = e / KQ, kq = e % KQ;
         const int gm = mn0 + mn, gk = k0 + 4 * kq;
         long row = gm < MN ? (long)gm : -1;
-        if (gather) row = gather[gm < MN ? gm : 0] | (gm < MN ? 0L : -1L);
+        if (gather) row = rows_cached ? grow[v] : (gather[gm < MN ? gm : 0] | (gm < MN ? 0L : -1L));
         bool rv = row >= 0;
         if (winL) { const int tpos = gm % winL + gk / winD - winPad; rv = rv && tpos >= 0 && tpos < winL; row -= winPad; }
         p = base + (rv ? row * ld + gk : 0);
