@@ -1219,18 +1219,56 @@ int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, in
     else conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("conv3x3_wgrad");
-  const long total = (long)9 * Cout * Cin + (db ? Cout : 0);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  wgrad_reduce_kernel<<<blocks, 256, 0, s>>>(p.slab, p.bslab, splits, Cout, Cin, dw, db, accumulate);
-  UMPR_LAUNCH_CHECK("wgrad_reduce");
-  return 0;
+  return umpr_wgrad_reduce(p.slab, p.bslab, splits, Cout, Cin, dw, db, accumulate, s);
 }
 
 // dW[co][ci][t] (+)= sum over splits of slab[split][t][co][ci]; db likewise from bslab (may be null)
+// The same with the splits shared out over 16 groups of a 1024-thread workgroup (64 outputs per workgroup): the 64- and
+// 128-channel layers have one or two output tiles and therefore 100+ splits, which one thread per output walks one dependent
+// load after the other (140 us per layer at the very end of the backward pass).  Fixed order: group g sums q = g, g+16, ...,
+// the groups are combined in order.
+__global__ __launch_bounds__(1024) void wgrad_reduce_wide_f32_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                                     int splits, int Cout, int Cin, float* __restrict__ dw,
+                                                                     float* __restrict__ db, int accumulate) {
+  __shared__ float red[16][64];
+  const long per = (long)9 * Cout * Cin;
+  const long total = per + (bslab ? Cout : 0);
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + c;
+  float v = 0.f;
+  if (i < per) {
+    for (int q = g; q < splits; q += 16) v += slab[(long)q * per + i];
+  } else if (i < total) {
+    for (int q = g; q < splits; q += 16) v += bslab[(long)q * Cout + (i - per)];
+  }
+  red[g][c] = v;
+  __syncthreads();
+  if (g == 0 && i < total) {
+    float r = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) r += red[k][c];
+    if (i < per) {
+      const int ci = (int)(i % Cin);
+      const long rr = i / Cin;
+      const int co = (int)(rr % Cout), t = (int)(rr / Cout);
+      float* d = dw + ((long)co * Cin + ci) * 9 + t;
+      *d = accumulate ? *d + r : r;
+    } else {
+      const int co = (int)(i - per);
+      db[co] = accumulate ? db[co] + r : r;
+    }
+  }
+}
+
 int umpr_wgrad_reduce(const float* slab, const float* bslab, int splits, int Cout, int Cin, float* dw, float* db,
                       int accumulate, hipStream_t s) {
   const long total = (long)9 * Cout * Cin + ((db && bslab) ? Cout : 0);
+  if (splits >= 32) {
+    wgrad_reduce_wide_f32_kernel<<<(unsigned)((total + 63) / 64), 1024, 0, s>>>(slab, (db && bslab) ? bslab : nullptr, splits,
+                                                                              Cout, Cin, dw, db, accumulate);
+    UMPR_LAUNCH_CHECK("wgrad_reduce_wide");
+    return 0;
+  }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   wgrad_reduce_kernel<<<blocks, 256, 0, s>>>(slab, (db && bslab) ? bslab : nullptr, splits, Cout, Cin, dw, db, accumulate);
