@@ -59,3 +59,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), f"{name} declared in include/umpr_hip.h but not exported"
     cdll.umpr_version.restype = ctypes.c_char_p
     assert b"gfx950" in cdll.umpr_version()
+
+
+def test_every_environment_switch_is_in_the_built_library():
+    """Each switch the sources read (umpr_env_on / umpr_env_int / getenv) must appear as a string in libumpr_hip.so.
+    Regression guard: hipcc once gave two namespace-scope lambdas that differed only in the getenv literal the same closure
+    symbol, and UMPR_WGRAD_STREAM silently read UMPR_FC_SMALL."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = open(os.path.join(root, "umpr_amd", "libumpr_hip.so"), "rb").read()
+    names = set()
+    for f in glob.glob(os.path.join(root, "umpr_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "umpr_amd", "csrc", "*.h")):
+        names |= set(re.findall(r'(?:getenv|umpr_env_on|umpr_env_int)\("([A-Z0-9_]+)"', open(f).read()))
+    assert len(names) >= 15, names
+    missing = sorted(n for n in names if n.encode() + b"\x00" not in blob)
+    assert not missing, missing

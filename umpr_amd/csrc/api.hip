@@ -20,7 +20,7 @@ void umpr_set_error(const char* fmt, ...) {
 // ---- profiling registry -------------------------------------------------------------------------------------
 namespace {
 // UMPR_FC_SMALL=0: batch-sized-M products stay on the tiled GEMM (A/B runs)
-const bool g_fc_small = [] { const char* v = getenv("UMPR_FC_SMALL"); return !(v && v[0] == '0'); }();
+const bool g_fc_small = umpr_env_on("UMPR_FC_SMALL");
 struct ProfRec { hipEvent_t e0, e1; int family; double work; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -589,7 +589,7 @@ struct WgradSide {
   }
 };
 WgradSide g_wside;
-const bool g_wgrad_side = [] { const char* v = getenv("UMPR_WGRAD_STREAM"); return !(v && v[0] == '0'); }();
+const bool g_wgrad_side = umpr_env_on("UMPR_WGRAD_STREAM");
 // host callback after the kernels of one VGG block's backward have been enqueued (data parallel: the caller starts that
 // block's gradient exchange while the blocks below are still being computed)
 umpr_block_callback g_block_cb = nullptr;

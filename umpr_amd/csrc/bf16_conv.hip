@@ -1453,14 +1453,14 @@ inline int grid_for(long n, int cap) {
 }
 
 // 1 (default): v_mfma_f32_16x16x32_bf16 form, 5-10 % faster per layer on MI355X (profiles/r02_k_m16_ab.txt); 0: 32x32x16 form
-const int g_b16_m16 = [] { const char* v = getenv("UMPR_B16_M16"); return v ? atoi(v) : 1; }();
+const int g_b16_m16 = umpr_env_int("UMPR_B16_M16", 1);
 
 // UMPR_B16_PP: ping-pong schedule in the 8-wave forward / dgrad kernels.  2 (default): where it measured faster - the
 // 256-channel tiles (wave tile 128 x 64, 32 MFMAs per phase: +8-10 %, 512->512@28 1158 TF) and the 1-D 128-channel tiles
 // (+3-5 %); the 2-D 128-channel tiles of the 112 x 112 maps (16 MFMAs per phase) lose 15 % to the second barrier.
 // 1: everywhere, 0: nowhere (profiles/r02_u_pp_ab.txt).
-const int g_b16_pp = [] { const char* v = getenv("UMPR_B16_PP"); return v ? atoi(v) : 2; }();
-const int g_b16_wm16 = [] { const char* v = getenv("UMPR_B16_WM16"); return v ? atoi(v) : 1; }();   // weight gradient likewise (+2 %)
+const int g_b16_pp = umpr_env_int("UMPR_B16_PP", 2);
+const int g_b16_wm16 = umpr_env_int("UMPR_B16_WM16", 1);   // weight gradient likewise (+2 %)
 
 template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3, int ABL = 0>
 void launch_conv(ConvB16Params p, hipStream_t s) {
@@ -1493,7 +1493,7 @@ void launch_conv(ConvB16Params p, hipStream_t s) {
 // UMPR_B16_CFG (A/B runs): tile for the layers with >= 256 output channels.  0: 256 px x 256 ch, 8 waves (one workgroup
 // per CU); 1: 256 x 128, 4 waves of 128 x 64 (80 KB of LDS: two workgroups per CU, their barriers interleave);
 // 2: 512 x 128, 8 waves of 128 x 64
-const int g_b16_cfg = [] { const char* v = getenv("UMPR_B16_CFG"); return v ? atoi(v) : 0; }();
+const int g_b16_cfg = umpr_env_int("UMPR_B16_CFG", 0);
 
 int conv_bn_for(int M, int W) {
   if (M % 256 == 0 && W != 14 && g_b16_cfg == 0) return 256;
@@ -1503,8 +1503,8 @@ int conv_bn_for(int M, int W) {
 template <int W, int TR, int TC, int TR2, int TC2>
 int dispatch_conv_w(const ConvB16Params& p, hipStream_t s) {
   const int BN = conv_bn_for(p.M, W);
-  static const int deep = [] { const char* v = getenv("UMPR_B16_D"); return v ? atoi(v) : 3; }();
-  static const int abl = [] { const char* v = getenv("UMPR_B16_ABL"); return v ? atoi(v) : 0; }();
+  static const int deep = umpr_env_int("UMPR_B16_D", 3);
+  static const int abl = umpr_env_int("UMPR_B16_ABL", 0);
   if (BN == 256 && W == 28 && abl == 1) launch_conv<W, TR, TC, 256, 2, 4, 3, 1>(p, s);
   else if (BN == 256 && W == 28 && abl == 2) launch_conv<W, TR, TC, 256, 2, 4, 3, 2>(p, s);
   else if (BN == 256 && W == 28 && abl == 3) launch_conv<W, TR, TC, 256, 2, 4, 3, 3>(p, s);

@@ -1066,7 +1066,7 @@ static bool g_conv_force_v1 = false;  // UMPR_CONV_V1=1 selects the generic gath
 static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; const char* q = getenv("UMPR_CONV_BN"); g_conv_bn = q ? atoi(q) : 0; const char* wq = getenv("UMPR_CONV_WINO"); g_conv_no_wino = wq && wq[0] == '0'; } } g_conv_env_init;
 static bool wino_layer(int H, int W) { return H == W && (W == 56 || W == 28 || W == 14); }
 // 112x112 maps with >= 128 channels on both sides (conv2_2): Winograd only in backward (UMPR_WINO_112=1, experiment)
-static const bool g_wino_112 = [] { const char* v = getenv("UMPR_WINO_112"); return v && v[0] == '1'; }();
+static const bool g_wino_112 = (umpr_env_int("UMPR_WINO_112", 0) == 1);
 static bool wino_bwd_layer(int C, int M, int H, int W) {
   return wino_layer(H, W) || (g_wino_112 && H == W && W == 112 && C >= 128 && M >= 128);
 }
@@ -1168,7 +1168,7 @@ static void wgrad_geometry(int W, int* R, int* CW) {
   else { *R = 1; *CW = 32; }
 }
 
-static const bool g_wgrad_wino = [] { const char* v = getenv("UMPR_WGRAD_WINO"); return !(v && v[0] == '0'); }();
+static const bool g_wgrad_wino = umpr_env_on("UMPR_WGRAD_WINO");
 static bool wgrad_wino_layer(int Cin, int Cout, int H, int W) {
   return g_wgrad_wino && !g_conv_force_v1 && wino_bwd_layer(Cin, Cout, H, W) && Cin >= 32 && Cout >= 32;
 }

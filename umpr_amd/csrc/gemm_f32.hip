@@ -239,7 +239,7 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   int BN = g.N <= 64 ? 64 : 128;
   // a grid that leaves CUs idle (the text path's [12800 x 128] x 128 products: 100 tiles of 128 x 128) takes smaller
   // tiles: each halving doubles the workgroups in flight
-  static const int small_grid = [] { const char* v = getenv("UMPR_GEMM_SMALL_GRID"); return v ? atoi(v) : 384; }();
+  static const int small_grid = umpr_env_int("UMPR_GEMM_SMALL_GRID", 384);
   // (not for the deep-K products that split K over workgroups below: there the split fills the chip and a smaller
   // tile only re-reads more - the [384 x 300] dW_ih products got 16 % slower with 64 x 64 tiles)
   const bool will_split = g.split_k != 1 && g.K >= 512;
@@ -252,8 +252,8 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
     const long tiles = (long)tm * tn;
     // batch-sized M (the VGG classifier at 64 images): the kernel streams a weight matrix once and is bound by memory
     // latency, not by the MFMA pipe or HBM - more workgroups in flight (3 fit a CU) hide it
-    static const int small_m_target = [] { const char* v = getenv("UMPR_GEMM_SMALL_M_WGS"); return v ? atoi(v) : 512; }();
-    static const int b16_target = [] { const char* v = getenv("UMPR_GEMM_B16_WGS"); return v ? atoi(v) : 512; }();
+    static const int small_m_target = umpr_env_int("UMPR_GEMM_SMALL_M_WGS", 512);
+    static const int b16_target = umpr_env_int("UMPR_GEMM_B16_WGS", 512);
     const int target = t_gemm_b16 ? b16_target : (g.M <= 64 ? small_m_target : 512);
     if (tiles < target / 2 && g.K >= 512) {
       split = (int)((target + tiles - 1) / tiles);

@@ -589,7 +589,7 @@ int umpr_colsum_rows(const float* src, int rows, long cols, long row_stride, flo
 }
 
 // UMPR_GRU_V1=1: the 64-sequence kernels (A/B runs)
-static const bool g_gru_v1 = [] { const char* v = getenv("UMPR_GRU_V1"); return v && v[0] == '1'; }();
+static const bool g_gru_v1 = (umpr_env_int("UMPR_GRU_V1", 0) == 1);
 
 int umpr_gru_recurrent_fwd(const float* gx, const float* whh_f, const float* bhh_f, const float* whh_r,
                            const float* bhh_r, const int* lengths, const int* order, const int* dst_row, float* out,

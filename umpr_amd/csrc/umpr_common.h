@@ -1,5 +1,6 @@
 // Shared device/host helpers for libumpr_hip (gfx950 / MI355X only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -28,6 +29,13 @@ void umpr_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Environment switches.  Plain functions on purpose: two namespace-scope `[] { getenv("A") ... }()` initialisers that differ
+// only in their string literal were given the same closure symbol by hipcc in api.hip, and the second switch silently read the
+// first one's variable (UMPR_WGRAD_STREAM=0 had no effect for half a round; tests/test_cabi_symbols.py now checks that every
+// getenv name of the sources is present in the built library).
+static inline bool umpr_env_on(const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); }
+static inline int umpr_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 // ---- device helpers --------------------------------------------------------------------------
 // v_mfma_f32_32x32x2_f32: A lane l -> A[i=l&31][k=l>>5], B lane l -> B[k=l>>5][j=l&31],

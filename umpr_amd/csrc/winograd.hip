@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_dma_kernel(WinoGemmParams 
         Mb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Tpad + wn * 64 + j * 32 + l31] = tot[i][j][r];
 }
 
-const int g_wino_dma = [] { const char* v = getenv("UMPR_WINO_DMA"); return v ? atoi(v) : 1; }();   // 0 off, 1: 32-deep stages, 2: 16-deep stages at 3 waves/SIMD
+const int g_wino_dma = umpr_env_int("UMPR_WINO_DMA", 1);   // 0 off, 1: 32-deep stages, 2: 16-deep stages at 3 waves/SIMD
 
 inline int nblk(long n, int cap) {
   long b = (n + 255) / 256;
@@ -554,7 +554,7 @@ size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W) {
 // UMPR_WINO_CHUNK_MB = budget for V + M of one chunk (0 = whole batch in one pass, the default).
 // Measured (batch 64, fp32 step): 0 -> 42.5 ms, 224 -> 45.3, 160 -> 46.5, 96 -> 50.7: the smaller GEMMs and the extra
 // launches cost more than on-die re-reads give back, so it stays an experiment switch (profiles/README.md, r02_n).
-static const long g_wino_chunk_mb = [] { const char* v = getenv("UMPR_WINO_CHUNK_MB"); return v ? atol(v) : 0L; }();
+static const long g_wino_chunk_mb = (long)umpr_env_int("UMPR_WINO_CHUNK_MB", 0);
 static int wino_chunk_images(int N, long floats_per_image) {
   if (g_wino_chunk_mb <= 0) return N;
   long nc = (g_wino_chunk_mb << 20) / (floats_per_image * 4);
