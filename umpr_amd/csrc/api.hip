@@ -116,9 +116,39 @@ int umpr_set_gemm_bf16(int on) { umpr_gemm_set_b16(on != 0); return 0; }
 size_t umpr_embed_gru_bidir_ws_bytes(int N, int L, int E) {
   const size_t tiles = umpr_gru_tiles(N);
   // gx / dgx [N*L*384] + dWhh slabs + bias slabs + split-K slab for dW_ih (forward: the stacked input weights) + the
-  // stacked [384][E] weight gradient
-  return ((size_t)N * L * 384 + tiles * 2 * G3 * H + tiles * 2 * 2 * G3 + (size_t)128 * G3 * E + (size_t)2 * G3 * E) * sizeof(float);
+  // stacked [384][E] weight gradient + the gathered embedding rows [N*L][E]
+  return ((size_t)N * L * 384 + tiles * 2 * G3 * H + tiles * 2 * 2 * G3 + (size_t)128 * G3 * E + (size_t)2 * G3 * E +
+          (size_t)N * L * E) * sizeof(float);
 }
+namespace {
+// The token rows of the embedding table, gathered ONCE into a contiguous [N*L][E] matrix (one wave per row, whole 1200-B rows)
+// instead of inside the projection GEMM, whose 128 x 128 tiles fetched 64-B pieces of random rows of the 480 MB table stage
+// by stage and three times over (one per column tile): 228 us for 260 MB at E = 300.  UMPR_EMB_GATHER=0: gather in the GEMM.
+const bool g_emb_gather = umpr_env_on("UMPR_EMB_GATHER");
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
+                                                          int E, float* __restrict__ out, long rows) {
+  const int lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+    const float* src = emb + ids[r] * (long)E;
+    float* dst = out + r * (long)E;
+    if ((E & 3) == 0) {
+      for (int c = lane; c < E / 4; c += 64) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(src)[c];
+    } else {
+      for (int c = lane; c < E; c += 64) dst[c] = src[c];
+    }
+  }
+}
+float* gathered_rows(float* ws, int N, int L, int E) {
+  return ws + (size_t)N * L * 384 + (size_t)umpr_gru_tiles(N) * (2 * G3 * H + 2 * 2 * G3) + (size_t)128 * G3 * E + (size_t)2 * G3 * E;
+}
+int gather_rows(const int64_t* ids, const float* emb, int E, float* out, long rows, hipStream_t s) {
+  long blocks = (rows + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  gather_rows_kernel<<<(unsigned)blocks, 256, 0, s>>>(ids, emb, E, out, rows);
+  UMPR_LAUNCH_CHECK("gather_rows");
+  return 0;
+}
+}  // namespace
 
 int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,
                              const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
@@ -142,7 +172,14 @@ int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,
       if (int rc = umpr_multi_copy(src, dst, cnt, nullptr, 4, s)) return rc;
     }
     UmprGemm g;
-    g.A = emb; g.lda = E; g.gatherA = ids; g.B = wst; g.ldb = E; g.transB = true;
+    if (g_emb_gather) {
+      float* xg = gathered_rows(ws, N, L, E);
+      if (int rc = gather_rows(ids, emb, E, xg, (long)N * L, s)) return rc;
+      g.A = xg; g.lda = E;
+    } else {
+      g.A = emb; g.lda = E; g.gatherA = ids;
+    }
+    g.B = wst; g.ldb = E; g.transB = true;
     g.C = gx; g.ldc = 384; g.M = N * L; g.N = 2 * G3; g.K = E; g.bias = bst; g.bias_mode = 1;
     if (int rc = umpr_gemm(g, s)) return rc;
   } else {
@@ -189,7 +226,14 @@ int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E, co
      // 192..383 are copied (or added) to their parameters' gradients
     float* stacked = kslab + (size_t)128 * G3 * E;
     UmprGemm g;
-    g.A = dgx; g.lda = 384; g.transA = true; g.B = emb; g.ldb = E; g.gatherB = ids;
+    g.A = dgx; g.lda = 384; g.transA = true;
+    if (g_emb_gather) {
+      float* xg = gathered_rows(ws, N, L, E);
+      if (int rc = gather_rows(ids, emb, E, xg, (long)N * L, S(stream))) return rc;
+      g.B = xg; g.ldb = E;
+    } else {
+      g.B = emb; g.ldb = E; g.gatherB = ids;
+    }
     g.C = stacked; g.ldc = E; g.M = 2 * G3; g.N = E; g.K = N * L; g.split_k = 0; g.ws = kslab;
     g.ws_bytes = (size_t)128 * G3 * E * sizeof(float);
     if (int rc = umpr_gemm(g, S(stream))) return rc;
