@@ -706,6 +706,71 @@ __global__ void wino_dy_pair_kernel(const float* __restrict__ dy, float* __restr
 }
 
 // db[m] = sum over n, y, x of dy[n][m][y][x], two fixed-order stages: one workgroup per (n, m) plane, then over n
+// The same with the splits shared out over four thread groups of a workgroup (64 input channels x 4 groups): the layers with
+// few output tiles have 16-32 splits, i.e. 256-512 slab loads per output for the one-thread-per-output form above
+// (350 us for the 32 768 outputs of 128->256).  Group g sums the splits q = g, g+4, ... in order; the groups are combined
+// in order through LDS.
+__global__ __launch_bounds__(256) void wino_wgrad_finish_wide_kernel(const float* __restrict__ P, int splits, int Mch, int C,
+                                                                     int Mpad, int Cpad, float* __restrict__ dw, int accumulate) {
+  __shared__ float red[3][16][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int chunks = (C + 63) / 64;
+  const int m = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + cl;
+  const long per = (long)Mpad * Cpad;
+  const bool ok = c < C;
+  float v[4][4];
+#pragma unroll
+  for (int a = 0; a < 16; ++a) {
+    float acc = 0.f;
+    if (ok)
+      for (int sp = g; sp < splits; sp += 4) acc += P[((long)sp * 16 + a) * per + (long)m * Cpad + c];
+    v[a >> 2][a & 3] = acc;
+  }
+  if (g > 0) {
+#pragma unroll
+    for (int a = 0; a < 16; ++a) red[g - 1][a][cl] = v[a >> 2][a & 3];
+  }
+  __syncthreads();
+  if (g != 0 || !ok) return;
+#pragma unroll
+  for (int a = 0; a < 16; ++a) v[a >> 2][a & 3] = ((v[a >> 2][a & 3] + red[0][a][cl]) + red[1][a][cl]) + red[2][a][cl];
+  float gv[3][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    gv[0][b] = v[0][b] + 0.5f * (v[1][b] + v[2][b]);
+    gv[1][b] = 0.5f * (v[1][b] - v[2][b]);
+    gv[2][b] = 0.5f * (v[1][b] + v[2][b]) + v[3][b];
+  }
+  float* d = dw + ((long)m * C + c) * 9;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float o0 = gv[a][0] + 0.5f * (gv[a][1] + gv[a][2]);
+    const float o1 = 0.5f * (gv[a][1] - gv[a][2]);
+    const float o2 = 0.5f * (gv[a][1] + gv[a][2]) + gv[a][3];
+    if (accumulate) { d[a * 3 + 0] += o0; d[a * 3 + 1] += o1; d[a * 3 + 2] += o2; }
+    else { d[a * 3 + 0] = o0; d[a * 3 + 1] = o1; d[a * 3 + 2] = o2; }
+  }
+}
+
+// db partial sums: one wave per (image, channel) plane, float4 loads, shuffle reduction (the workgroup-per-plane tree above
+// spends most of its time in eight barriers for 3 KB of data)
+__global__ __launch_bounds__(256) void wino_bias_part_wave_kernel(const float* __restrict__ dy, float* __restrict__ part, long HW,
+                                                                  long planes) {
+  const int lane = threadIdx.x & 63;
+  const long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pl >= planes) return;
+  const float4* src = reinterpret_cast<const float4*>(dy + pl * HW);
+  float a0 = 0.f, a1 = 0.f;
+  long i = lane;
+  for (; i + 64 < HW / 4; i += 128) {
+    const float4 u = src[i], w = src[i + 64];
+    a0 += (u.x + u.y) + (u.z + u.w); a1 += (w.x + w.y) + (w.z + w.w);
+  }
+  for (; i < HW / 4; i += 64) { const float4 u = src[i]; a0 += (u.x + u.y) + (u.z + u.w); }
+  const float a = wave_sum(a0 + a1);
+  if (lane == 0) part[pl] = a;
+}
+
 __global__ void wino_bias_part_kernel(const float* __restrict__ dy, float* __restrict__ part, long HW) {
   __shared__ float red[256];
   const float4* src = reinterpret_cast<const float4*>(dy + (long)blockIdx.x * HW);   // plane index = n * Mch + m
@@ -970,12 +1035,16 @@ static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db
     wino_wgrad_gemm_kernel<<<(unsigned)(16 * g.MT * g.CT * g.splits), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_wgrad_gemm");
-  wino_wgrad_finish_kernel<<<nblk((long)Cout * Cin, 4096), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad, dw, accumulate);
+  if (g.splits >= 8)
+    wino_wgrad_finish_wide_kernel<<<(unsigned)((long)Cout * ((Cin + 63) / 64)), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad,
+                                                                                         dw, accumulate);
+  else
+    wino_wgrad_finish_kernel<<<nblk((long)Cout * Cin, 4096), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad, dw, accumulate);
   UMPR_LAUNCH_CHECK("wino_wgrad_finish");
   if (db) {  // P is free again after the finish kernel (same stream): N * Cout partial sums fit in it
     UMPR_REQUIRE((size_t)N * Cout <= (size_t)g.splits * 16 * g.Mpad * g.Cpad && ((long)H * W) % 4 == 0,
                  "winograd wgrad: bias-gradient scratch");
-    wino_bias_part_kernel<<<(unsigned)((long)N * Cout), 256, 0, s>>>(dy, P, (long)H * W);
+    wino_bias_part_wave_kernel<<<(unsigned)(((long)N * Cout + 3) / 4), 256, 0, s>>>(dy, P, (long)H * W, (long)N * Cout);
     UMPR_LAUNCH_CHECK("wino_bias_part");
     wino_bias_sum_kernel<<<(Cout + 255) / 256, 256, 0, s>>>(P, db, N, Cout, accumulate);
     UMPR_LAUNCH_CHECK("wino_bias_sum");
