@@ -349,3 +349,73 @@ def test_zero_grad_skips_in_place_gradients():
             assert not getattr(p, "_umpr_fresh", False) and float(p.grad.abs().max()) == 0.0, name
     covered = sum(hi - lo for g in opt.groups for lo, hi in g.zero_ranges) + sum(p.numel() for g in opt.groups for p in g.direct)
     assert covered == sum(g.numel for g in opt.groups)
+
+
+class _TinyVgg(torch.nn.Module):
+    """Parameter names of the real model (``...features.N.weight`` at torchvision's conv indices, a classifier) at toy
+    sizes: what GradReducer._find_block_slices keys on."""
+
+    def __init__(self):
+        super().__init__()
+        self.v = torch.nn.Module()
+        convs = {0: (3, 4), 2: (4, 4), 5: (4, 6), 7: (6, 6), 10: (6, 8), 12: (8, 8), 14: (8, 8), 17: (8, 8), 19: (8, 8),
+                 21: (8, 8), 24: (8, 8), 26: (8, 8), 28: (8, 8)}
+        self.v.features = torch.nn.ModuleList(
+            [torch.nn.Conv2d(*convs[i], 3, padding=1) if i in convs else torch.nn.Identity() for i in range(31)])
+        self.v.classifier = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 5))
+
+    def forward(self, x):
+        for m in self.v.features:
+            x = torch.tanh(m(x)) if isinstance(m, torch.nn.Conv2d) else x
+        return self.v.classifier(x.mean((2, 3)))
+
+
+def _block_bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from umpr_amd import parallel
+    from umpr_amd.optim import FusedAdam
+    parallel.init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    model = _TinyVgg()
+    opt = FusedAdam(model, 1e-3, 1e-3)
+    red = parallel.GradReducer(opt, n_buckets=2)
+    # five contiguous, disjoint slices of the weight arena, one per VGG block, in front of nothing they overlap
+    assert sorted(red.block_slices) == [0, 1, 2, 3, 4], red.block_slices
+    spans = sorted(red.block_slices.values())
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), spans
+    g = torch.Generator().manual_seed(7 + rank)
+    x = torch.randn(3, 3, 6, 6, generator=g)
+    torch.manual_seed(0)
+    twin = _TinyVgg()                                       # same weights, no reducer: the un-reduced local gradients
+    topt = FusedAdam(twin, 1e-3, 1e-3)
+    for it in range(2):
+        opt.zero_grad()
+        model(x).pow(2).sum().backward()                    # the early classifier bucket starts inside this backward
+        topt.zero_grad()
+        twin(x).pow(2).sum().backward()
+        ref = [a.clone() for a in topt.grad_arenas()]
+        # what the feature backward's callback does on the GPU: block 4 first, block 0 last, each exactly once
+        for b in (4, 3, 2, 1, 0):
+            red._on_block(b)
+        assert len(red.reduced) == 5
+        red.finish()                                        # the complement of the five block ranges (+ early slice)
+        for r in ref:
+            dist.all_reduce(r)
+        for a, r in zip(opt.grad_arenas(), ref):
+            assert torch.allclose(a, r, atol=1e-6), (it, (a - r).abs().max())   # every element reduced exactly once
+        assert red.reduced == [] and red.handles == []
+    if rank == 0:
+        torch.save({"ok": torch.tensor(1)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_block_gradient_buckets_gloo(tmp_path):
+    """The per-VGG-block buckets of GradReducer (started from the feature backward's C callback on the GPU) on two gloo
+    ranks: block ranges are disjoint arena slices, and blocks + early classifier slice + finish() reduce every gradient
+    element exactly once."""
+    out = str(tmp_path / "blocks.pt")
+    mp.spawn(_block_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert os.path.exists(out)
