@@ -31,6 +31,7 @@ struct GemmParams {
   int split_k; int k_per_split; float* ws;
   int vecA, vecB;
   int waL, waD, waP, wbL, wbD, wbP;   // sliding-window operands (UmprGemm::winA / winB), L == 0: off
+  int pf2;                            // bf16 path: two stages of global loads in flight (UMPR_GEMM_B16_PF2=0: one)
 };
 
 // B16 (mixed-precision mode, text path): operands stay fp32 in memory and are rounded to bf16 when a stage is written to
@@ -81,6 +82,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   }
   __syncthreads();
   const int l31 = lane & 31, kh = lane >> 5;
+  if (B16 && p.pf2) {
+    // bf16 path: the MFMA work of a stage is a few hundred cycles, the stage is bound by the latency of its global loads -
+    // so TWO stages are kept in flight (register sets ra / ra2 alternate; the loop is unrolled by two so that both are
+    // named at compile time).  One accumulation chain: the two-level fold below exists for fp32 operand accuracy.
+    LA ra2 = ra;
+    LB rb2 = rb;
+    auto mfma_stage = [&](int cur) {
+#pragma unroll
+      for (int ks = 0; ks < BKS / 16; ++ks) {
+        gemm_bf16x8 ah[TM], bh[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[i] = LA::frag_b16(Ah[cur], wm * WTM + i * 32, lane, ks);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bh[j] = LB::frag_b16(Bh[cur], wn * WTN + j * 32, lane, ks);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) tot[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], tot[i][j], 0, 0, 0);
+      }
+    };
+    if (nt > 1) {
+      ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg + BKS, kend, p.vecA, tid, p.waL, p.waD, p.waP);
+      rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg + BKS, kend, p.vecB, tid, p.wbL, p.wbD, p.wbP);
+    }
+    for (int t = 0; t < nt; t += 2) {
+      // LDS[0] holds stage t, ra / rb stage t + 1 (in flight)
+      if (t + 2 < nt) {
+        ra2.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg + (t + 2) * BKS, kend, p.vecA, tid, p.waL, p.waD, p.waP);
+        rb2.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg + (t + 2) * BKS, kend, p.vecB, tid, p.wbL, p.wbD, p.wbP);
+      }
+      mfma_stage(0);
+      if (t + 1 < nt) { ra.store_b16(Ah[1], tid); rb.store_b16(Bh[1], tid); }
+      __syncthreads();
+      if (t + 1 >= nt) break;
+      // LDS[1] holds stage t + 1, ra2 / rb2 stage t + 2 (in flight)
+      if (t + 3 < nt) {
+        ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg + (t + 3) * BKS, kend, p.vecA, tid, p.waL, p.waD, p.waP);
+        rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg + (t + 3) * BKS, kend, p.vecB, tid, p.wbL, p.wbD, p.wbP);
+      }
+      mfma_stage(1);
+      if (t + 2 < nt) { ra2.store_b16(Ah[0], tid); rb2.store_b16(Bh[0], tid); }
+      __syncthreads();
+    }
+  } else
   // outer loop = one MFMA accumulation chain (KFLUSH stages): inside it the accumulators are written only by
   // MFMAs and stay in AGPRs (a conditional fold inside the stage loop made hipcc move all of them through VGPRs
   // every stage: 128 v_accvgpr moves + an MFMA pipeline drain per stage)
@@ -231,6 +276,8 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   UMPR_REQUIRE(!(g.winA_L && (g.transA || g.gatherA || (g.winA_D & 3))) && !(g.winB_L && (g.transB || g.gatherB || (g.winB_D & 3))),
                "gemm: a sliding-window operand must be row-major, ungathered, with a row length that is a multiple of 4");
   UMPR_REQUIRE((!g.winA_L || g.lda == g.winA_D) && (!g.winB_L || g.ldb == g.winB_D), "gemm: window operand with a padded row pitch");
+  static const int b16_pf2 = umpr_env_int("UMPR_GEMM_B16_PF2", 1);
+  p.pf2 = b16_pf2;
   p.waL = g.winA_L; p.waD = g.winA_D; p.waP = g.winA_pad; p.wbL = g.winB_L; p.wbD = g.winB_D; p.wbP = g.winB_pad;
   // float4 staging needs 16-B aligned rows and a contiguous extent that is a multiple of 4 (no partial vectors)
   p.vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && (((g.transA ? g.M : g.K) & 3) == 0);
