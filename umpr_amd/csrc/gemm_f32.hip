@@ -31,7 +31,6 @@ struct GemmParams {
   int split_k; int k_per_split; float* ws;
   int vecA, vecB;
   int waL, waD, waP, wbL, wbD, wbP;   // sliding-window operands (UmprGemm::winA / winB), L == 0: off
-  int pf2;                            // bf16 path: two stages of global loads in flight (UMPR_GEMM_B16_PF2=0: one)
 };
 
 // B16 (mixed-precision mode, text path): operands stay fp32 in memory and are rounded to bf16 when a stage is written to
@@ -39,8 +38,11 @@ struct GemmParams {
 // fp32 accumulation and epilogue unchanged.  The kernel is then bound by its global loads, not by the matrix pipe.
 typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
 
+// Registers: the fp32 form holds two accumulator sets (chain + running total) and sits at 244-308 VGPR+AGPR, i.e. one or two
+// workgroups per CU; the bf16 form needs one set and two staging sets (~170): three workgroups per CU, which is what hides its
+// global-load latency (at 308 registers - one workgroup per CU - it was no faster than the fp32 form: tools/bench_gemm.py).
 template <int BM, int BN, bool TA, bool TB, bool B16 = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, B16 && BM * BN < 128 * 128 ? 3 : 2) void gemm_f32_kernel(GemmParams p) {
   constexpr int BKS = BK;   // k-depth of a stage (32 for the bf16 path measured slower: 10.23-10.29 vs 10.08-10.13 ms per step)
   using LA = TileRegs<BM, !TA, BKS>;  // A non-trans is k-contiguous
   using LB = TileRegs<BN, TB, BKS>;   // B trans is k-contiguous
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   }
   __syncthreads();
   const int l31 = lane & 31, kh = lane >> 5;
-  if (B16 && p.pf2) {
+  if constexpr (B16) {
     // bf16 path: the MFMA work of a stage is a few hundred cycles, the stage is bound by the latency of its global loads -
     // so TWO stages are kept in flight (register sets ra / ra2 alternate; the loop is unrolled by two so that both are
     // named at compile time).  One accumulation chain: the two-level fold below exists for fp32 operand accuracy.
@@ -142,23 +144,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     if (t + 1 < nt) {
       ra.load(p.A, p.lda, p.gatherA, m0, p.M, kbeg + (t + 1) * BKS, kend, p.vecA, tid, p.waL, p.waD, p.waP);
       rb.load(p.B, p.ldb, p.gatherB, n0, p.N, kbeg + (t + 1) * BKS, kend, p.vecB, tid, p.wbL, p.wbD, p.wbP);
-    }
-    if constexpr (B16) {
-#pragma unroll
-      for (int ks = 0; ks < BKS / 16; ++ks) {
-        gemm_bf16x8 ah[TM], bh[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) ah[i] = LA::frag_b16(Ah[cur], wm * WTM + i * 32, lane, ks);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bh[j] = LB::frag_b16(Bh[cur], wn * WTN + j * 32, lane, ks);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-      }
-      if (t + 1 < nt) { ra.store_b16(Ah[cur ^ 1], tid); rb.store_b16(Bh[cur ^ 1], tid); }
-      __syncthreads();
-      continue;
     }
     const float* as = As[cur] + wm * WTM + l31;
     const float* bs = Bs[cur] + wn * WTN + l31;
@@ -276,8 +261,6 @@ int umpr_gemm(const UmprGemm& g, hipStream_t stream) {
   UMPR_REQUIRE(!(g.winA_L && (g.transA || g.gatherA || (g.winA_D & 3))) && !(g.winB_L && (g.transB || g.gatherB || (g.winB_D & 3))),
                "gemm: a sliding-window operand must be row-major, ungathered, with a row length that is a multiple of 4");
   UMPR_REQUIRE((!g.winA_L || g.lda == g.winA_D) && (!g.winB_L || g.ldb == g.winB_D), "gemm: window operand with a padded row pitch");
-  static const int b16_pf2 = umpr_env_int("UMPR_GEMM_B16_PF2", 1);
-  p.pf2 = b16_pf2;
   p.waL = g.winA_L; p.waD = g.winA_D; p.waP = g.winA_pad; p.wbL = g.winB_L; p.wbD = g.winB_D; p.wbP = g.winB_pad;
   // float4 staging needs 16-B aligned rows and a contiguous extent that is a multiple of 4 (no partial vectors)
   p.vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && (((g.transA ? g.M : g.K) & 3) == 0);
