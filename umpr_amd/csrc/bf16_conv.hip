@@ -1495,6 +1495,10 @@ void launch_conv(ConvB16Params p, hipStream_t s) {
 // 2: 512 x 128, 8 waves of 128 x 64
 const int g_b16_cfg = umpr_env_int("UMPR_B16_CFG", 0);
 
+// UMPR_B16_T64=1: the 64-channel output tiles of the 224 / 112 maps take 512 pixels (8 waves, one workgroup per CU) instead of
+// 256 (4 waves, two per CU): half the weight re-reads from L2 per output pixel (A/B)
+const int g_b16_t64 = umpr_env_int("UMPR_B16_T64", 0);
+
 int conv_bn_for(int M, int W) {
   if (M % 256 == 0 && W != 14 && g_b16_cfg == 0) return 256;
   return M % 128 == 0 ? 128 : 64;
@@ -1513,6 +1517,7 @@ int dispatch_conv_w(const ConvB16Params& p, hipStream_t s) {
   else if (BN == 128 && p.M % 256 == 0 && W != 14 && g_b16_cfg == 1) launch_conv<W, TR, TC, 128, 2, 2>(p, s);
   else if (BN == 128 && p.M % 256 == 0 && W != 14 && g_b16_cfg == 2) launch_conv<W, TR2, TC2, 128, 4, 2>(p, s);
   else if (BN == 128) launch_conv<W, TR, TC, 128, 4, 2>(p, s);
+  else if (p.M % 64 == 0 && g_b16_t64 && TR2 > 0) launch_conv<W, TR2, TC2, 64, 8, 1>(p, s);   // 512-pixel tiles, 8 waves
   else if (p.M % 64 == 0) launch_conv<W, TR, TC, 64, 4, 1>(p, s);
   else return -1;
   return 0;
