@@ -648,185 +648,8 @@ struct WgradB16Params {
 
 // segment: 1-D (TR == 0): TC consecutive flat pixels; 2-D: TR rows x TC real columns.  Workgroup tile = 32*WCO output
 // channels x 32*WCI input channels x 9 taps; KSW wave groups split the k-steps of every segment between them.
-template <int W, int TR, int TC, int WCO, int WCI, int KSW>
-__global__ __launch_bounds__(64 * WCO * WCI * KSW) void wgrad_bf16_kernel(WgradB16Params p) {
-  constexpr int NW = WCO * WCI * KSW, NT = 64 * NW;
-  constexpr bool TWO_D = TR > 0;
-  constexpr int KP = TWO_D ? TR * TC : TC;        // pixels per segment
-  constexpr int RW = W + 1;
-  constexpr int LP = TC + 2;
-  constexpr int TS = TWO_D ? LP : RW;
-  constexpr int PATCH = TWO_D ? (TR + 2) * LP : KP + 2 * RW + 2;
-  constexpr int PPP = (PATCH + 63) / 64;
-  constexpr int PPX = PPP * 64 + 4;               // +4 pixels: plane stride off the 256-B bank period (tr reads)
-  constexpr int KPX = KP + 4;
-  constexpr int GPL = 4 * WCO, XPL = 4 * WCI;     // dY planes / x planes of the tile
-  constexpr int GPC = GPL * (KP / 64), XPC = XPL * PPP;
-  constexpr int NPC = GPC + XPC;                  // DMA pieces per segment
-  constexpr int PCW = (NPC + NW - 1) / NW;
-  constexpr int GB = GPL * KPX * 8, XB = XPL * PPX * 8;   // elements per stage
-  constexpr int KSTEPS = KP / 16, KSL = KSTEPS / KSW;
-  static_assert(KP % 64 == 0 && KSTEPS % KSW == 0 && (!TWO_D || (W % TC == 0 && TC % 16 == 0)), "segment shape");
-  constexpr int RED = KSW > 1 ? (WCO * WCI * 9 * 16 * 64 + WCO * WCI * 32) * 2 : 0;   // fp32 exchange of the wave groups, in bf16 units
-  constexpr int SMEM = 2 * (GB + XB) > RED ? 2 * (GB + XB) : RED;
-  __shared__ __attribute__((aligned(1024))) bf16_t smem[SMEM];
-  bf16_t* const Gs = smem;                         // [2][GB]
-  bf16_t* const Xs = smem + 2 * GB;                // [2][XB]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ksw = wave / (WCO * WCI), wt = wave % (WCO * WCI);
-  const int wco = wt / WCI, wci = wt % WCI;
-  // workgroups of one split read the same pixels: keep them on one XCD (splits is a multiple of 8 or the tail idles)
-  const int xcd = blockIdx.x & 7;
-  const long qq = blockIdx.x >> 3;
-  const int tile = (int)(qq % p.ntiles);
-  const int split = (int)(qq / p.ntiles) * 8 + xcd;
-  if (split >= p.splits) return;
-  const int cot = tile / p.ncit, cit = tile % p.ncit;
-  const long sbeg = (long)split * p.segs_per_split;
-  const long send = min(p.nseg, sbeg + p.segs_per_split);
-
-  // ---- DMA plan: piece q of a segment; q < GPC: dY plane q / (KP/64), 64 pixels; else x plane, patch piece
-  const bf16_t* src0[PCW]; unsigned dst0[PCW]; int isx[PCW];
-#pragma unroll
-  for (int i = 0; i < PCW; ++i) {
-    const int q = (wave + NW * i) % NPC;
-    if (q < GPC) {
-      const int pl = q / (KP / 64), pp = q % (KP / 64);
-      const int k = pp * 64 + lane;
-      const long gp = TWO_D ? (long)(k / TC) * RW + (k % TC) : k;
-      src0[i] = p.dy + ((long)(cot * GPL + pl) * p.dps + gp) * 8;
-      dst0[i] = lds_addr(Gs) + (unsigned)(pl * KPX + pp * 64) * 16u;
-      isx[i] = 0;
-    } else {
-      const int q2 = q - GPC;
-      const int pl = q2 / PPP, pp = q2 % PPP;
-      int u = pp * 64 + lane;
-      long gp;
-      if (TWO_D) {
-        if (u > PATCH - 1) u = PATCH - 1;
-        const int a = u / LP, b = u - a * LP;
-        gp = (long)(a - 1) * RW + (b - 1);
-      } else {
-        gp = u - RW - 1;
-      }
-      src0[i] = p.x + ((long)(cit * XPL + pl) * p.xps + gp) * 8;
-      dst0[i] = lds_addr(Xs) + (unsigned)(pl * PPX + pp * 64) * 16u;
-      isx[i] = 1;
-    }
-  }
-  auto seg_origin = [&](long seg) -> long {
-    if (TWO_D) {
-      constexpr int CT = W / TC;
-      const long band = seg / CT;
-      return band * TR * RW + 1 + (seg - band * CT) * TC;
-    }
-    return seg * KP;
-  };
-  auto issue = [&](long seg, int buf) {
-    const long q0 = seg_origin(seg) * 8;
-#pragma unroll
-    for (int i = 0; i < PCW; ++i)
-      glds16(src0[i] + q0, dst0[i] + (unsigned)buf * (isx[i] ? XB * 2u : GB * 2u));
-  };
-
-  // ---- fragment addresses.  16-lane group g handles matrix rows/columns 16*(g&1).. and k-half g>>1; inside a group lane
-  // 4q+p supplies the address of k-row q, columns 4p..4p+3 (two planes x 8 channels per group).  Wave group ksw works
-  // on the k-steps kk*KSW + ksw: its 16-pixel offset (one patch row when a segment row holds a single k-step) is part
-  // of the lane base, so every k-step / tap offset below is a compile-time immediate.
-  const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const int kl = 8 * (g >> 1) + q4;                                  // + 4 for the second read of a k-step
-  const int kadv_g = ksw * 16;
-  const int kadv_x = ksw * ((TWO_D && TC == 16) ? LP : 16);
-  const unsigned abase = (unsigned)((wco * 4 + 2 * (g & 1) + (p4 >> 1)) * KPX + kl + kadv_g) * 16u + (p4 & 1) * 8u;
-  const unsigned bbase = (unsigned)((wci * 4 + 2 * (g & 1) + (p4 >> 1)) * PPX + kl + kadv_x) * 16u + (p4 & 1) * 8u;
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int x = 0; x < 16; ++x) acc[t][x] = 0.f;
-  // bias gradient: the A fragment of a lane is 8 pixels of ONE output channel (row l & 31 of the wave's 32) - the waves
-  // with input-channel position 0 of the ci-tile-0 workgroups add them up on the side (16 VALU per 9 MFMAs)
-  const bool do_bias = p.bslab != nullptr && cit == 0 && wci == 0;   // wave-uniform
-  float bsum = 0.f;
-
-  if (sbeg < send) issue(sbeg, 0);
-  wait_vm<0>();
-  __syncthreads();
-  for (long seg = sbeg; seg < send; ++seg) {
-    const int cur = (int)(seg - sbeg) & 1;
-    issue(seg + 1 < send ? seg + 1 : seg, cur ^ 1);      // the last segment re-loads itself: uniform DMA count
-    const char* gs = reinterpret_cast<const char*>(Gs) + cur * (GB * 2) + abase;
-    const char* xs = reinterpret_cast<const char*>(Xs) + cur * (XB * 2) + bbase;
-#pragma unroll
-    for (int kk = 0; kk < KSL; ++kk) {
-      constexpr int dummy = 0; (void)dummy;
-      const int ko = kk * KSW * 16;                      // first pixel of wave group 0's k-step in the dY image
-      const int xo = TWO_D ? (ko / TC + 1) * LP + (ko % TC) + 1 : ko + RW + 1;   // ... and in the x patch (centre tap)
-      bf16x8 a;
-      {
-        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(gs + ko * 16));
-        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(gs + (ko + 4) * 16));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] = a0[e]; a[4 + e] = a1[e]; }
-      }
-      if (do_bias) {
-        float s4 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s4 += (float)a[e];
-        bsum += s4;
-      }
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int toff = ((t / 3) - 1) * TS + (t % 3) - 1;
-        const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(xs + (xo + toff) * 16));
-        const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(xs + (xo + toff + 4) * 16));
-        bf16x8 b;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { b[e] = b0[e]; b[4 + e] = b1[e]; }
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-      }
-    }
-    wait_vm<0>();
-    __syncthreads();
-  }
-
-  // ---- combine the KSW wave groups through LDS, then store the slab tile: D[co][ci], lanes run along ci
-  bsum += __shfl_xor(bsum, 32, 64);                    // the two k-halves of a channel
-  if (KSW > 1) {
-    float* red = reinterpret_cast<float*>(smem);       // [WCO*WCI][9][16][64] floats = 36 KB per wave, then [WCO*WCI][32]
-    if (ksw == 1) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int x = 0; x < 16; ++x) red[((wt * 9 + t) * 16 + x) * 64 + lane] = acc[t][x];
-      if (lane < 32) red[WCO * WCI * 9 * 16 * 64 + wt * 32 + lane] = bsum;
-    }
-    __syncthreads();
-    if (ksw == 0) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int x = 0; x < 16; ++x) acc[t][x] += red[((wt * 9 + t) * 16 + x) * 64 + lane];
-      bsum += red[WCO * WCI * 9 * 16 * 64 + wt * 32 + (lane & 31)];
-    }
-  }
-  if (ksw == 0) {
-    const int r = lane & 31, h = lane >> 5;
-    const int ci = cit * 32 * WCI + wci * 32 + r;
-#pragma unroll
-    for (int x = 0; x < 16; ++x) {
-      const int co = cot * 32 * WCO + wco * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-      float* o = p.slab + (((long)split * p.Cout + co) * p.Cin + ci) * 9;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) o[t] = acc[t][x];
-    }
-    if (do_bias && lane < 32) p.bslab[(long)split * p.Cout + cot * 32 * WCO + wco * 32 + lane] = bsum;
-  }
-}
-
+// (The first version of this kernel used v_mfma_f32_32x32x16_bf16 with 16-pixel k-steps; the 16x16x32 form below replaced it
+// after the A/B in profiles/r02_k_m16_ab.txt: +2 %.)
 // The weight gradient on v_mfma_f32_16x16x32_bf16: a k-step is 32 pixels, a wave's 32 x 32 channel tile is 2 x 2 MFMA
 // tiles per tap (same LDS bytes and MFMA cycles as the 32x32x16 form, higher sustained clock).
 template <int W, int TR, int TC, int WCO, int WCI, int KSW>
@@ -1460,7 +1283,6 @@ const int g_b16_m16 = umpr_env_int("UMPR_B16_M16", 1);
 // (+3-5 %); the 2-D 128-channel tiles of the 112 x 112 maps (16 MFMAs per phase) lose 15 % to the second barrier.
 // 1: everywhere, 0: nowhere (profiles/r02_u_pp_ab.txt).
 const int g_b16_pp = umpr_env_int("UMPR_B16_PP", 2);
-const int g_b16_wm16 = umpr_env_int("UMPR_B16_WM16", 1);   // weight gradient likewise (+2 %)
 
 template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3, int ABL = 0>
 void launch_conv(ConvB16Params p, hipStream_t s) {
@@ -1548,8 +1370,7 @@ template <int W, int TR, int TC, int WCO, int WCI, int KSW>
 void launch_wgrad(WgradB16Params p, const WgradPlan& q, hipStream_t s) {
   p.nseg = q.nseg; p.ncit = q.ncit; p.ntiles = q.ntiles; p.splits = q.splits; p.segs_per_split = q.segs_per_split;
   const long blocks = (long)((q.splits + 7) / 8) * 8 * q.ntiles;
-  if (g_b16_wm16) wgrad_bf16_m16_kernel<W, TR, TC, WCO, WCI, KSW><<<dim3((unsigned)blocks), 64 * WCO * WCI * KSW, 0, s>>>(p);
-  else wgrad_bf16_kernel<W, TR, TC, WCO, WCI, KSW><<<dim3((unsigned)blocks), 64 * WCO * WCI * KSW, 0, s>>>(p);
+  wgrad_bf16_m16_kernel<W, TR, TC, WCO, WCI, KSW><<<dim3((unsigned)blocks), 64 * WCO * WCI * KSW, 0, s>>>(p);
 }
 
 }  // namespace
