@@ -15,7 +15,8 @@ from ._lib import lib, stream_ptr
 
 import os
 
-_EARLY_ADAM = os.environ.get("UMPR_EARLY_ADAM", "1") == "1"
+# "1" (default): on; "0": off.
+_EARLY_ADAM = os.environ.get("UMPR_EARLY_ADAM", "1")
 
 
 def _is_classifier(name):
@@ -99,11 +100,10 @@ class FusedAdam:
 
     def arm_early(self, grad_scale=1.0):
         """train_step: the coming backward belongs to exactly one optimiser step with this gradient scale.
-        UMPR_EARLY_ADAM=0 turns it off.  Worth little on one GPU (the HBM-bound Adam kernel competes with the convolutions
-        it runs beside: 42.57 vs 42.44 ms) and 0.3-0.5 ms per step behind the all-reduce in the RCCL rehearsal (43.16 vs
-        43.49 ms fp32, 16.06 vs 16.51 ms bf16).  Its stream is one more next to main / text / weight-gradient / RCCL:
+        UMPR_EARLY_ADAM=0 turns it off.  Worth 0.3-0.5 ms per step behind the all-reduce in the RCCL rehearsal (43.16 vs
+        43.49 ms fp32, 16.06 vs 16.51 ms bf16); on a single GPU 0.1-0.3 ms in bf16 (9.56 vs 9.71 ms) and nothing in fp32.  Its stream is one more next to main / text / weight-gradient / RCCL:
         umpr_amd/__init__.py raises GPU_MAX_HW_QUEUES so that they do not share hardware queues."""
-        if not _EARLY_ADAM:
+        if _EARLY_ADAM == "0":
             return
         self._early = (float(grad_scale),)
         self._early_done = None
@@ -127,7 +127,13 @@ class FusedAdam:
         _, lo, hi, _ = eb
         dev = g.p.device
         if self._early_stream is None:
-            self._early_stream = torch.cuda.Stream(dev)
+            # Without a gradient exchange the update rides on the library's weight-gradient stream (Adam is HBM-bound, the
+            # weight-gradient kernels behind it MFMA-bound): a sixth stream of its own - main, text, weight-gradient, copy
+            # and this one - cost 1.8 ms (bf16) / 3.7 ms (fp32) per step as soon as per-step uploads ran on a copy stream
+            # (bench.py --h2d: 11.6 vs 9.79 ms, 45.3 vs 41.4 ms).  Behind an all-reduce it keeps its own stream: the
+            # weight-gradient kernels must not queue behind the collective.
+            ws = lib().fn["umpr_vgg16_wgrad_stream"]() if not handles else None
+            self._early_stream = torch.cuda.ExternalStream(ws, device=dev) if ws else torch.cuda.Stream(dev)
         main = torch.cuda.current_stream(dev)
         self._early_stream.wait_stream(main)            # the gradients were written on the backward's stream
         with torch.cuda.stream(self._early_stream):
