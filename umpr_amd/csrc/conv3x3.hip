@@ -1079,7 +1079,7 @@ size_t umpr_conv3x3_pack_floats(int N, int Cin, int Cout, int H, int W) {
   size_t m = a > b ? a : b;
   if (c > m) m = c;
   if (wino_bwd_layer(Cin, Cout, H, W) && !g_conv_no_wino) {
-    const size_t f = umpr_wino_ws_floats(N, Cin, Cout, H, W), t = umpr_wino_ws_floats(N, Cout, Cin, H, W);
+    const size_t f = umpr_wino_ws_floats(N, Cin, Cout, H, W, 0), t = umpr_wino_ws_floats(N, Cout, Cin, H, W, 1);
     if (f > m) m = f;
     if (t > m) m = t;
   }
@@ -1097,7 +1097,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
   const int C = transposed ? Cout : Cin;   // reduction channels
   const long NP = (long)N * H * W;
   if ((transposed ? wino_bwd_layer(C, M, H, W) : wino_layer(H, W)) && !g_conv_no_wino && !g_conv_force_v1 && wpack && C >= 32 &&
-      wpack_floats >= umpr_wino_ws_floats(N, C, M, H, W)) {
+      wpack_floats >= umpr_wino_ws_floats(N, C, M, H, W, transposed)) {
     // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs; timed under the same family with the direct conv's FLOP count
     UmprProfScope prof(transposed ? UMPR_K_CONV_DGRAD : UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
     return umpr_wino_conv3x3(x, w, transposed, bias, mask, y, N, Cin, Cout, H, W, relu, wpack, wpack_floats, s);

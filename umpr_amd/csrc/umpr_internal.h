@@ -69,7 +69,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
                      int N, int Cin, int Cout, int H, int W, int relu, float* wpack, size_t wpack_floats,
                      hipStream_t s);
 // winograd.hip
-size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W);
+size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W, int transposed);
 size_t umpr_wino_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W);
 int umpr_wino_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
                     int accumulate, float* ws, size_t ws_floats, hipStream_t s);

@@ -277,6 +277,164 @@ __global__ void wino_output_pair_kernel(const float* __restrict__ Mx, const floa
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// F(4x4,3x3): 6x6 input tile -> 4x4 outputs, 36 planes.  4x fewer multiplies than the direct convolution (F(2x2,3x3):
+// 2.25x) and V / M are 2.25x the activation they transform instead of 4x - both the GEMM and the HBM-bound transforms
+// shrink.  Used where the map is a multiple of 4 (56x56, 28x28).  The price is rounding: the transform matrices hold
+// 4, 5, 8 and 1/24, so the fp32 result is 4-7e-6 of max|y| from the float64 convolution where the direct kernel and
+// F(2x2,3x3) are at 2-4e-7 (tools/wino43_error.py) - inside the 2e-5 per-layer bound of test_conv3x3.
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino4_bt(const float d0, const float d1, const float d2, const float d3, const float d4,
+                                         const float d5, float* __restrict__ o) {
+  o[0] = 4.f * d0 - 5.f * d2 + d4;
+  o[1] = -4.f * (d1 + d2) + d3 + d4;
+  o[2] = 4.f * (d1 - d2) - d3 + d4;
+  o[3] = 2.f * (d3 - d1) - d2 + d4;
+  o[4] = 2.f * (d1 - d3) - d2 + d4;
+  o[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+
+// U[xi][mt][s][k][m_local], xi = 6a + b: the image order of wino_weights_kernel with 36 planes
+__global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int M, int C, int CinW,
+                                     int transposed) {
+  const int MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
+  const long total = (long)MT * WBM * S * WK;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ml = (int)(i % WBM);
+    long r = i / WBM;
+    const int k = (int)(r % WK); r /= WK;
+    const int s = (int)(r % S);
+    const int mt = (int)(r / S);
+    const int m = mt * WBM + ml, c = s * WK + k;
+    float g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = 0.f;
+      if (m < M && c < C) v = transposed ? w[((long)c * CinW + m) * 9 + 8 - t] : w[((long)m * CinW + c) * 9 + t];
+      g[t] = v;
+    }
+    float gg[6][3];   // G g
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+      gg[0][j] = 0.25f * g0;
+      gg[1][j] = (-1.f / 6.f) * (g0 + g1 + g2);
+      gg[2][j] = (-1.f / 6.f) * (g0 - g1 + g2);
+      gg[3][j] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      gg[4][j] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      gg[5][j] = g2;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const float g0 = gg[a][0], g1 = gg[a][1], g2 = gg[a][2];
+      float* dst = U + (long)(a * 6) * total + i;
+      dst[0] = 0.25f * g0;
+      dst[total] = (-1.f / 6.f) * (g0 + g1 + g2);
+      dst[2 * total] = (-1.f / 6.f) * (g0 - g1 + g2);
+      dst[3 * total] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      dst[4 * total] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      dst[5 * total] = g2;
+    }
+  }
+}
+
+// V[xi][c][t] (c < Cpad),  t = (n*TH + ty)*TW + tx over 4x4 output tiles,  d = x[n][c][4ty-1 .. 4ty+4][4tx-1 .. 4tx+4]
+// One thread per (c, t): per input row one aligned float4 and the two halo scalars; 36 stores, each coalesced over t.
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C,
+                                                          int Cpad, int H, int W, long Tpad, long Tw) {
+  const int TH = H / 4, TW = W / 4;
+  const long T = (long)N * TH * TW;
+  const long total = (long)Cpad * Tw;
+  const long per = (long)Cpad * Tpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i % Tw;
+    const int c = (int)(i / Tw);
+    float* dst = V + (long)c * Tpad + t;
+    if (t >= T || c >= C) {
+#pragma unroll
+      for (int a = 0; a < 36; ++a) dst[(long)a * per] = 0.f;
+      continue;
+    }
+    const int tx = (int)(t % TW);
+    const long r = t / TW;
+    const int ty = (int)(r % TH), n = (int)(r / TH);
+    const float* src = x + ((long)n * C + c) * H * W;
+    const int x0 = 4 * tx;
+    const bool okl = x0 > 0, okr = x0 + 4 < W;
+    float e[6][6];   // e[a] = (row a of d) B  - the horizontal transform, applied as each row arrives
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int yy = 4 * ty - 1 + a;
+      const bool oky = yy >= 0 && yy < H;
+      const float* row = src + (oky ? yy * W : 0) + x0;
+      const float l = row[okl ? -1 : 0];
+      const float4 m = *reinterpret_cast<const float4*>(row);
+      const float rr = row[okr ? 4 : 0];
+      wino4_bt(oky && okl ? l : 0.f, oky ? m.x : 0.f, oky ? m.y : 0.f, oky ? m.z : 0.f, oky ? m.w : 0.f,
+               oky && okr ? rr : 0.f, e[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      float o[6];
+      wino4_bt(e[0][b], e[1][b], e[2][b], e[3][b], e[4][b], e[5][b], o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dst[(long)(a * 6 + b) * per] = o[a];
+    }
+  }
+}
+
+// y[n][m][4ty+i][4tx+j] = epilogue( (A^T M A)[i][j] ): 36 loads coalesced over t, one float4 store per output row
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
+                                                           const float* __restrict__ mask, float* __restrict__ y, int N,
+                                                           int Mch, int H, int W, long Tpad, int Mpad, int relu) {
+  const int TH = H / 4, TW = W / 4;
+  const long T = (long)N * TH * TW;
+  const long total = (long)Mch * T;
+  const long per = (long)Mpad * Tpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i % T;
+    const int m = (int)(i / T);
+    const int tx = (int)(t % TW);
+    const long r = t / TW;
+    const int ty = (int)(r % TH), n = (int)(r / TH);
+    const float* src = Mx + (long)m * Tpad + t;
+    float am[4][6];   // A^T M, accumulated plane row by plane row
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      float q[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) q[a] = src[(long)(a * 6 + b) * per];
+      const float s12 = q[1] + q[2], d12 = q[1] - q[2], s34 = q[3] + q[4], d34 = q[3] - q[4];
+      am[0][b] = q[0] + s12 + s34;
+      am[1][b] = d12 + 2.f * d34;
+      am[2][b] = s12 + 4.f * s34;
+      am[3][b] = d12 + 8.f * d34 + q[5];
+    }
+    const float bv = bias ? bias[m] : 0.f;
+    const long ob = (((long)n * Mch + m) * H + 4 * ty) * W + 4 * tx;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float s12 = am[a][1] + am[a][2], d12 = am[a][1] - am[a][2], s34 = am[a][3] + am[a][4], d34 = am[a][3] - am[a][4];
+      float v[4] = {am[a][0] + s12 + s34 + bv, d12 + 2.f * d34 + bv, s12 + 4.f * s34 + bv, d12 + 8.f * d34 + am[a][5] + bv};
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      const long oo = ob + (long)a * W;
+      if (mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(mask + oo);
+        v[0] = mk.x > 0.f ? v[0] : 0.f; v[1] = mk.y > 0.f ? v[1] : 0.f;
+        v[2] = mk.z > 0.f ? v[2] : 0.f; v[3] = mk.w > 0.f ? v[3] : 0.f;
+      }
+      *reinterpret_cast<float4*>(y + oo) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
 static long wino_tpad(long T) { return (T + WBN - 1) / WBN * WBN; }
 
 struct WinoGemmParams {
@@ -287,6 +445,7 @@ struct WinoGemmParams {
   long Tpad;        // >= TT * 128
   long TT;          // 128-wide tile columns
   int Mpad;         // MT * 128
+  int planes;       // 16: F(2x2,3x3), 36: F(4x4,3x3) - the leading dimension of U / V / Mx
 };
 
 // grid.x = 16 * TT * MT, XCD-aware: the MT workgroups that share one V tile get consecutive slots on one XCD
@@ -306,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmParams p) {
   const long qq = blockIdx.x >> 3;
   const int mt = (int)(qq % p.MT);
   const long bt = (qq / p.MT) * 8 + xcd;     // (xi, t-tile) index
-  if (bt >= 16 * TT) return;
+  if (bt >= p.planes * TT) return;
   const int xi = (int)(bt / TT);
   const long t0 = (bt % TT) * WBN;
   const float* Ub = p.U + (((long)xi * p.MT + mt) * p.S) * (WK * WBM);
@@ -435,7 +594,7 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_dma_kernel(WinoGemmParams 
   const long qq = blockIdx.x >> 3;
   const int mt = (int)(qq % p.MT);
   const long bt = (qq / p.MT) * 8 + xcd;
-  if (bt >= 16 * TT) return;
+  if (bt >= p.planes * TT) return;
   const int xi = (int)(bt / TT);
   const long t0 = (bt % TT) * WBN;
   const float* Ub = p.U + (((long)xi * p.MT + mt) * p.S) * (WK * WBM);
@@ -539,12 +698,25 @@ inline int nblk(long n, int cap) {
 
 }  // namespace
 
-// workspace: U [16][MT*128][S*32] + V [16][S*32][Tpad] + M [16][MT*128][Tpad]  (floats)
-size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W) {
-  const long T = (long)N * (H / 2) * (W / 2);
+// UMPR_WINO_F4: 0 = F(2x2,3x3) everywhere; 1 (default) = F(4x4,3x3) for the data gradient only; 2 = forward as well.
+// The backward pass is linear in its inputs (the ReLU / pool decisions were taken in forward), so the larger tile's
+// rounding stays a 5e-6 perturbation of the gradient.  In FORWARD the same rounding flips 15x more ReLU / max-pool
+// decisions than the direct kernel's 3e-7 does: predictions stay within 3e-6 of the reference, but the first layers'
+// gradients move to 5e-3 relative L2 from the float64 run where the reference's own fp32 is at 1.5e-3
+// (golden umpr_full_V1_B2_randnM) - outside the parity bound, hence opt-in (36.6 instead of 39 ms per step).
+static const int g_wino_f4 = umpr_env_int("UMPR_WINO_F4", 1);
+static inline bool wino_f4_map(int H, int W, int transposed) {
+  return g_wino_f4 >= (transposed ? 1 : 2) && (H % 4) == 0 && (W % 4) == 0;
+}
+
+// workspace: U [P][MT*128][S*32] + V [P][S*32][Tpad] + M [P][MT*128][Tpad]  (floats);  P = 16 planes over 2x2 tiles, or
+// 36 planes over 4x4 tiles where the map allows F(4x4,3x3)
+size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W, int transposed) {
+  const bool f4 = wino_f4_map(H, W, transposed);
+  const long T = f4 ? (long)N * (H / 4) * (W / 4) : (long)N * (H / 2) * (W / 2);
   const long Tpad = wino_tpad(T);
   const long MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
-  return (size_t)16 * (MT * WBM * S * WK + S * WK * Tpad + MT * WBM * Tpad) + 64;
+  return (size_t)(f4 ? 36 : 16) * (MT * WBM * S * WK + S * WK * Tpad + MT * WBM * Tpad) + 64;
 }
 
 // Image chunking: V and M (each 4x the activation they transform) are written by one kernel and read back by the next.
@@ -572,7 +744,7 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
 int umpr_wino_conv3x3(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
                       int N, int Cin, int Cout, int H, int W, int relu, float* ws, size_t ws_floats, hipStream_t s) {
   const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
-  UMPR_REQUIRE(ws_floats >= umpr_wino_ws_floats(N, C, M, H, W), "winograd: workspace too small");
+  UMPR_REQUIRE(ws_floats >= umpr_wino_ws_floats(N, C, M, H, W, transposed), "winograd: workspace too small");
   const int nc = wino_chunk_images(N, (long)16 * (C + M) * (H / 2) * (W / 2));
   for (int n0 = 0; n0 < N; n0 += nc) {
     const int n = N - n0 < nc ? N - n0 : nc;
@@ -589,33 +761,40 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
   UMPR_REQUIRE((H % 2) == 0 && (W % 2) == 0, "winograd: odd map %dx%d", H, W);
   const int M = transposed ? Cin : Cout;
   const int C = transposed ? Cout : Cin;
-  UMPR_REQUIRE(ws_floats >= umpr_wino_ws_floats(N, C, M, H, W), "winograd: workspace too small");
-  const long T = (long)N * (H / 2) * (W / 2);
+  UMPR_REQUIRE(ws_floats >= umpr_wino_ws_floats(N, C, M, H, W, transposed), "winograd: workspace too small");
+  const bool f4 = wino_f4_map(H, W, transposed);
+  const int planes = f4 ? 36 : 16;
+  const long T = f4 ? (long)N * (H / 4) * (W / 4) : (long)N * (H / 2) * (W / 2);
   const long Tpad = wino_tpad(T);
   const int MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
   float* U = ws;
-  float* V = U + (size_t)16 * MT * WBM * S * WK;
-  float* Mx = V + (size_t)16 * S * WK * Tpad;
+  float* V = U + (size_t)planes * MT * WBM * S * WK;
+  float* Mx = V + (size_t)planes * S * WK * Tpad;
   if (!weights_ready) {
-    wino_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
+    if (f4) wino4_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
+    else wino_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
     UMPR_LAUNCH_CHECK("wino_weights");
   }
   const long TT = (T + WBN - 1) / WBN;
-  if ((W / 2) % 2 == 0)
+  if (f4)
+    wino4_input_kernel<<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
+  else if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)S * WK * TT * WBN / 2, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
   else
     wino_input_kernel<<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
   UMPR_LAUNCH_CHECK("wino_input");
-  WinoGemmParams p{U, V, Mx, MT, S, C, Tpad, TT, MT * WBM};
-  const long groups = (16 * TT + 7) / 8 * 8;
+  WinoGemmParams p{U, V, Mx, MT, S, C, Tpad, TT, MT * WBM, planes};
+  const long groups = (planes * TT + 7) / 8 * 8;
   {
-    UmprProfScope prof(UMPR_K_WINO_GEMM, 2.0 * 16 * (double)M * C * T, s);
+    UmprProfScope prof(UMPR_K_WINO_GEMM, 2.0 * planes * (double)M * C * T, s);
     if (g_wino_dma == 2) wino_gemm_dma_kernel<16, 3><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
     else if (g_wino_dma) wino_gemm_dma_kernel<32, 2><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
     else wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_gemm");
-  if ((W / 2) % 2 == 0)
+  if (f4)
+    wino4_output_kernel<<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
+  else if ((W / 2) % 2 == 0)
     wino_output_pair_kernel<<<nblk((long)M * T / 2, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
   else
     wino_output_kernel<<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
@@ -793,19 +972,113 @@ __global__ void wino_bias_sum_kernel(const float* __restrict__ part, float* __re
   db[m] = accumulate ? db[m] + a : a;
 }
 
+// F(3x3,4x4), the weight-gradient counterpart of F(4x4,3x3):  dW = G^T [ sum_t (A g_t A^T) .* (B^T d_t B) ] G  with g_t the 4x4
+// tile of the output gradient, d_t the 6x6 input tile, A = (A^T)^T (6x4), G (6x3) as above: 36 GEMMs over a quarter of the
+// tiles - 4x fewer multiplies than the direct weight gradient (F(3x3,2x2): 2.25x).
+// Gy[xi][m][t] = (A g A^T)[xi];  columns t in [T, Tw) are written as zeros
+__device__ __forceinline__ void wino4_a(const float g0, const float g1, const float g2, const float g3, float* __restrict__ o) {
+  const float s02 = g0 + g2, s13 = g1 + g3, e = g0 + 4.f * g2, f = 2.f * g1 + 8.f * g3;
+  o[0] = g0; o[1] = s02 + s13; o[2] = s02 - s13; o[3] = e + f; o[4] = e - f; o[5] = g3;
+}
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Gy, int N, int Mch, int H,
+                                                       int W, long Tpad, long Tw, int Mpad) {
+  const int TH = H / 4, TW = W / 4;
+  const long T = (long)N * TH * TW;
+  const long total = (long)Mch * Tw;
+  const long per = (long)Mpad * Tpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i % Tw;
+    const int m = (int)(i / Tw);
+    float* dst = Gy + (long)m * Tpad + t;
+    if (t >= T) {
+#pragma unroll
+      for (int a = 0; a < 36; ++a) dst[(long)a * per] = 0.f;
+      continue;
+    }
+    const int tx = (int)(t % TW);
+    const long r = t / TW;
+    const int ty = (int)(r % TH), n = (int)(r / TH);
+    const float* src = dy + (((long)n * Mch + m) * H + 4 * ty) * W + 4 * tx;
+    float e[4][6];   // (row of g) A^T
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float4 g = *reinterpret_cast<const float4*>(src + (long)a * W);
+      wino4_a(g.x, g.y, g.z, g.w, e[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      float o[6];
+      wino4_a(e[0][b], e[1][b], e[2][b], e[3][b], o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dst[(long)(a * 6 + b) * per] = o[a];
+    }
+  }
+}
+
+// dw[m][c][3][3] (+)= G^T (sum_split P[split][.][m][c]) G for 36 planes; the splits are shared out over four thread groups
+// (q = g, g+4, ... in order) and the groups combined in order through LDS, as in wino_wgrad_finish_wide_kernel
+__device__ __forceinline__ void wino4_gt(const float* __restrict__ v, int stride, float* __restrict__ o) {
+  const float s12 = v[stride] + v[2 * stride], d12 = v[2 * stride] - v[stride];
+  const float s34 = v[3 * stride] + v[4 * stride], d34 = v[3 * stride] - v[4 * stride];
+  o[0] = 0.25f * v[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+  o[1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+  o[2] = (1.f / 6.f) * (s34 - s12) + v[5 * stride];
+}
+__global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __restrict__ P, int splits, int Mch, int C, int Mpad,
+                                                                 int Cpad, float* __restrict__ dw, int accumulate) {
+  __shared__ float red[3][36][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int chunks = (C + 63) / 64;
+  const int m = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + cl;
+  const long per = (long)Mpad * Cpad;
+  const bool ok = c < C;
+  float v[36];
+#pragma unroll
+  for (int a = 0; a < 36; ++a) {
+    float acc = 0.f;
+    if (ok)
+      for (int sp = g; sp < splits; sp += 4) acc += P[((long)sp * 36 + a) * per + (long)m * Cpad + c];
+    v[a] = acc;
+  }
+  if (g > 0) {
+#pragma unroll
+    for (int a = 0; a < 36; ++a) red[g - 1][a][cl] = v[a];
+  }
+  __syncthreads();
+  if (g != 0 || !ok) return;
+#pragma unroll
+  for (int a = 0; a < 36; ++a) v[a] = ((v[a] + red[0][a][cl]) + red[1][a][cl]) + red[2][a][cl];
+  float gv[3][6];   // G^T v (over the plane row index), per plane column b
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    float o[3];
+    wino4_gt(v + b, 6, o);
+    gv[0][b] = o[0]; gv[1][b] = o[1]; gv[2][b] = o[2];
+  }
+  float* d = dw + ((long)m * C + c) * 9;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float o[3];
+    wino4_gt(gv[a], 1, o);
+    if (accumulate) { d[a * 3 + 0] += o[0]; d[a * 3 + 1] += o[1]; d[a * 3 + 2] += o[2]; }
+    else { d[a * 3 + 0] = o[0]; d[a * 3 + 1] = o[1]; d[a * 3 + 2] = o[2]; }
+  }
+}
+
 struct WinoWgradParams {
-  const float* Gy;   // [16][Mpad][Tpad]
-  const float* V;    // [16][Cpad][Tpad]
-  float* P;          // [splits][16][Mpad][Cpad]
+  const float* Gy;   // [planes][Mpad][Tpad]
+  const float* V;    // [planes][Cpad][Tpad]
+  float* P;          // [splits][planes][Mpad][Cpad]
   int MT, CT, Mpad, Cpad;
   long Tpad;
   int stages;            // Tpad / 32
   int stages_per_split;
+  int planes;            // 16: F(3x3,2x2), 36: F(3x3,4x4)
 };
 
 constexpr int WLDT = 130;   // LDS row pitch of the transposed ([k][row]) operand images
 
-// grid.x = 16 * MT * CT * splits.  Both operands arrive k-contiguous ([row][t]); each thread loads float4 along t and
+// grid.x = planes * MT * CT * splits.  Both operands arrive k-contiguous ([row][t]); each thread loads float4 along t and
 // scatters the four values into the [k][row] image the MFMA fragment reads expect (scalar LDS stores, 2-way at most).
 __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams p) {
   constexpr int LD = WLDT;
@@ -821,8 +1094,8 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
   long b = blockIdx.x;
   const int ct = (int)(b % p.CT); b /= p.CT;
   const int mt = (int)(b % p.MT); b /= p.MT;
-  const int xi = (int)(b % 16);
-  const int split = (int)(b / 16);
+  const int xi = (int)(b % p.planes);
+  const int split = (int)(b / p.planes);
   const int s_begin = split * p.stages_per_split;
   const int s_end = min(p.stages, s_begin + p.stages_per_split);
   const int ns = s_end - s_begin;   // >= 1 by construction
@@ -922,7 +1195,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
 #pragma unroll
       for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
   }
-  float* Pb = p.P + ((((long)split * 16 + xi) * p.Mpad + mt * WBM) * p.Cpad) + ct * WBN;
+  float* Pb = p.P + ((((long)split * p.planes + xi) * p.Mpad + mt * WBM) * p.Cpad) + ct * WBN;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -968,15 +1241,17 @@ __global__ void wino_wgrad_finish_kernel(const float* __restrict__ P, int splits
 
 constexpr int kWinoWgradTargetWgs = 1024;
 
-struct WinoWgradGeom { long T, Tpad; int MT, CT, Mpad, Cpad, stages, splits, stages_per_split; };
+struct WinoWgradGeom { long T, Tpad; int MT, CT, Mpad, Cpad, stages, splits, stages_per_split, planes; };
 WinoWgradGeom wino_wgrad_geom(int N, int Cin, int Cout, int H, int W) {
   WinoWgradGeom g;
-  g.T = (long)N * (H / 2) * (W / 2);
+  const bool f4 = wino_f4_map(H, W, 1);
+  g.planes = f4 ? 36 : 16;
+  g.T = f4 ? (long)N * (H / 4) * (W / 4) : (long)N * (H / 2) * (W / 2);
   g.Tpad = wino_tpad(g.T);
   g.MT = (Cout + WBM - 1) / WBM; g.CT = (Cin + WBN - 1) / WBN;
   g.Mpad = g.MT * WBM; g.Cpad = g.CT * WBN;
   g.stages = (int)(g.Tpad / WK);
-  const int tiles = 16 * g.MT * g.CT;
+  const int tiles = g.planes * g.MT * g.CT;
   int splits = (kWinoWgradTargetWgs + tiles - 1) / tiles;
   const int max_splits = g.stages / 8 > 0 ? g.stages / 8 : 1;   // at least 8 stages (256 tiles) per workgroup
   if (splits > max_splits) splits = max_splits;
@@ -988,10 +1263,10 @@ WinoWgradGeom wino_wgrad_geom(int N, int Cin, int Cout, int H, int W) {
 
 }  // namespace
 
-// workspace: Gy [16][Mpad][Tpad] + V [16][Cpad][Tpad] + P [splits][16][Mpad][Cpad]  (floats)
+// workspace: Gy [planes][Mpad][Tpad] + V [planes][Cpad][Tpad] + P [splits][planes][Mpad][Cpad]  (floats)
 size_t umpr_wino_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W) {
   const WinoWgradGeom g = wino_wgrad_geom(N, Cin, Cout, H, W);
-  return (size_t)16 * ((size_t)g.Mpad * g.Tpad + (size_t)g.Cpad * g.Tpad + (size_t)g.splits * g.Mpad * g.Cpad) + 64;
+  return (size_t)g.planes * ((size_t)g.Mpad * g.Tpad + (size_t)g.Cpad * g.Tpad + (size_t)g.splits * g.Mpad * g.Cpad) + 64;
 }
 
 static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
@@ -1015,34 +1290,42 @@ static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db
   UMPR_REQUIRE(ws_floats >= umpr_wino_wgrad_ws_floats(N, Cin, Cout, H, W), "winograd wgrad: workspace too small");
   const WinoWgradGeom g = wino_wgrad_geom(N, Cin, Cout, H, W);
   float* Gy = ws;
-  float* V = Gy + (size_t)16 * g.Mpad * g.Tpad;
-  float* P = V + (size_t)16 * g.Cpad * g.Tpad;
-  // rows m >= Cout of Gy are never written: they only feed rows of P that the finish kernel does not read, but they
-  // must be finite?  No: every P element is a dot product of ONE Gy row with ONE V row, so garbage stays in its row.
-  if ((W / 2) % 2 == 0)
+  float* V = Gy + (size_t)g.planes * g.Mpad * g.Tpad;
+  float* P = V + (size_t)g.planes * g.Cpad * g.Tpad;
+  const bool f4 = g.planes == 36;
+  // rows m >= Cout of Gy are never written: every P element is a dot product of ONE Gy row with ONE V row, so garbage
+  // stays in rows of P that the finish kernel does not read.
+  if (f4)
+    wino4_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
+  else if ((W / 2) % 2 == 0)
     wino_dy_pair_kernel<<<nblk((long)Cout * g.Tpad / 2, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   else
     wino_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   UMPR_LAUNCH_CHECK("wino_dy");
-  if ((W / 2) % 2 == 0)
+  if (f4)
+    wino4_input_kernel<<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
+  else if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)g.Cpad * g.Tpad / 2, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
   else
     wino_input_kernel<<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
   UMPR_LAUNCH_CHECK("wino_input(wgrad)");
-  WinoWgradParams p{Gy, V, P, g.MT, g.CT, g.Mpad, g.Cpad, g.Tpad, g.stages, g.stages_per_split};
+  WinoWgradParams p{Gy, V, P, g.MT, g.CT, g.Mpad, g.Cpad, g.Tpad, g.stages, g.stages_per_split, g.planes};
   {
-    UmprProfScope prof(UMPR_K_WINO_WGRAD_GEMM, 2.0 * 16 * (double)Cout * Cin * g.T, s);
-    wino_wgrad_gemm_kernel<<<(unsigned)(16 * g.MT * g.CT * g.splits), 256, 0, s>>>(p);
+    UmprProfScope prof(UMPR_K_WINO_WGRAD_GEMM, 2.0 * g.planes * (double)Cout * Cin * g.T, s);
+    wino_wgrad_gemm_kernel<<<(unsigned)(g.planes * g.MT * g.CT * g.splits), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_wgrad_gemm");
-  if (g.splits >= 8)
+  if (f4)
+    wino4_wgrad_finish_kernel<<<(unsigned)((long)Cout * ((Cin + 63) / 64)), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad, dw,
+                                                                                     accumulate);
+  else if (g.splits >= 8)
     wino_wgrad_finish_wide_kernel<<<(unsigned)((long)Cout * ((Cin + 63) / 64)), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad,
                                                                                          dw, accumulate);
   else
     wino_wgrad_finish_kernel<<<nblk((long)Cout * Cin, 4096), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad, dw, accumulate);
   UMPR_LAUNCH_CHECK("wino_wgrad_finish");
   if (db) {  // P is free again after the finish kernel (same stream): N * Cout partial sums fit in it
-    UMPR_REQUIRE((size_t)N * Cout <= (size_t)g.splits * 16 * g.Mpad * g.Cpad && ((long)H * W) % 4 == 0,
+    UMPR_REQUIRE((size_t)N * Cout <= (size_t)g.splits * g.planes * g.Mpad * g.Cpad && ((long)H * W) % 4 == 0,
                  "winograd wgrad: bias-gradient scratch");
     wino_bias_part_wave_kernel<<<(unsigned)(((long)N * Cout + 3) / 4), 256, 0, s>>>(dy, P, (long)H * W, (long)N * Cout);
     UMPR_LAUNCH_CHECK("wino_bias_part");
