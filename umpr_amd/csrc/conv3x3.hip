@@ -1065,10 +1065,15 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_c3_kernel(ConvParams p) {
 static bool g_conv_force_v1 = false;  // UMPR_CONV_V1=1 selects the generic gather kernel (A/B runs)
 static struct ConvEnvInit { ConvEnvInit() { const char* e = getenv("UMPR_CONV_V1"); g_conv_force_v1 = e && e[0] == '1'; const char* q = getenv("UMPR_CONV_BN"); g_conv_bn = q ? atoi(q) : 0; const char* wq = getenv("UMPR_CONV_WINO"); g_conv_no_wino = wq && wq[0] == '0'; } } g_conv_env_init;
 static bool wino_layer(int H, int W) { return H == W && (W == 56 || W == 28 || W == 14); }
-// 112x112 maps with >= 128 channels on both sides (conv2_2): Winograd only in backward (UMPR_WINO_112=1, experiment)
-static const bool g_wino_112 = (umpr_env_int("UMPR_WINO_112", 0) == 1);
+// 112x112 maps with >= 128 channels on both sides (conv2_2): Winograd in backward only, and only on the F(4x4,3x3) tile -
+// with F(2x2,3x3) the 4x activation-sized transform traffic ate the gain (+1 %); on the larger tile the data gradient and the
+// weight gradient of that layer together save 1.7 ms per step (36.4 -> 34.7 ms).  UMPR_WINO_112 = 0 / 1 overrides.
+static bool wino_112() {
+  static const int v = umpr_env_int("UMPR_WINO_112", -1);
+  return v == 1 || (v < 0 && umpr_wino_f4_mode() >= 1);
+}
 static bool wino_bwd_layer(int C, int M, int H, int W) {
-  return wino_layer(H, W) || (g_wino_112 && H == W && W == 112 && C >= 128 && M >= 128);
+  return wino_layer(H, W) || (wino_112() && H == W && W == 112 && C >= 128 && M >= 128);
 }
 
 // scratch floats a conv call needs: the packed weights, or (deep layers) the Winograd U / V / M buffers

@@ -70,6 +70,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
                      hipStream_t s);
 // winograd.hip
 size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W, int transposed);
+int umpr_wino_f4_mode();   // UMPR_WINO_F4: 0 = F(2x2,3x3) only, 1 = F(4x4,3x3) in the backward pass, 2 = forward as well
 size_t umpr_wino_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W);
 int umpr_wino_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
                     int accumulate, float* ws, size_t ws_floats, hipStream_t s);

@@ -704,9 +704,12 @@ inline int nblk(long n, int cap) {
 // decisions than the direct kernel's 3e-7 does: predictions stay within 3e-6 of the reference, but the first layers'
 // gradients move to 5e-3 relative L2 from the float64 run where the reference's own fp32 is at 1.5e-3
 // (golden umpr_full_V1_B2_randnM) - outside the parity bound, hence opt-in (36.6 instead of 39 ms per step).
-static const int g_wino_f4 = umpr_env_int("UMPR_WINO_F4", 1);
+int umpr_wino_f4_mode() {
+  static const int mode = umpr_env_int("UMPR_WINO_F4", 1);   // function-local: also read by conv3x3.hip's initialisers
+  return mode;
+}
 static inline bool wino_f4_map(int H, int W, int transposed) {
-  return g_wino_f4 >= (transposed ? 1 : 2) && (H % 4) == 0 && (W % 4) == 0;
+  return umpr_wino_f4_mode() >= (transposed ? 1 : 2) && (H % 4) == 0 && (W % 4) == 0;
 }
 
 // workspace: U [P][MT*128][S*32] + V [P][S*32][Tpad] + M [P][MT*128][Tpad]  (floats);  P = 16 planes over 2x2 tiles, or
