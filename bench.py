@@ -16,6 +16,9 @@ launch stream inside the timed region (libumpr_hip's umpr_profile_*):
   fp32 full model : the Winograd batched GEMM (wino_gemm_dma_kernel) - `achieved` = the MFMA FLOPs it EXECUTES / its time;
                     `algorithmic_frac` prices the conv forward family by direct-convolution FLOPs (Winograd layers
                     execute 1/2.25 of those) and `model_frac` the whole step by SURVEY 8(d)'s 93.73 GFLOP per sample.
+                    Both are ALGORITHMIC rates and may exceed 1: the forward pass of the 56/28/14 layers executes 1/2.25
+                    of its direct-convolution FLOPs (F(2x2,3x3)), the backward pass of the 112/56/28 layers 1/4
+                    (F(4x4,3x3) / F(3x3,4x4)).  Only `frac` is an MFMA utilisation.
   bf16 full model : the bf16 implicit-GEMM convolution (forward launches), executed = algorithmic FLOPs.
   UMPR-R          : the recurrent GRU kernels (HBM / latency bound), algorithmic bytes / time against 8 TB/s.
 `cpu_baseline` times the oracle (oracle/umpr_ref.py, the CPU restatement pinned to the reference) on this box's host
@@ -330,8 +333,9 @@ def main():
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note
                     + "; the figure is per conv-forward layer call (transforms + GEMM), of which this kernel is the GEMM",
-                    "kernel": "wino_gemm_dma_kernel (Winograd F(2x2,3x3) batched GEMM of the 56/28/14 layers, forward "
-                              "and data gradient; largest share of GPU time).  achieved = MFMA FLOPs it executes / its "
+                    "kernel": "wino_gemm_dma_kernel (Winograd batched GEMM: 16 planes of F(2x2,3x3) for the forward pass of the "
+                              "56/28/14 layers, 36 planes of F(4x4,3x3) for the data gradient of the 112/56/28 layers; "
+                              "largest share of GPU time).  achieved = MFMA FLOPs it executes / its "
                               "HIP-event time on its launch stream; in the timed region it shares the chip with the "
                               "weight-gradient stream and the text stream",
                     "launches": n, "avg_launch_ms": ms / max(n, 1),
@@ -387,6 +391,10 @@ def main():
             gf = 3 * 2 * (TEXT_MMAC_FWD.get(args.emb, 150.6) + args.views * VGG_MMAC_FWD) / 1e3   # GFLOP per sample, training
             out["model_tflops"] = value * (gf / 3.0 if args.eval else gf) / 1e3 / world
             out["roofline"]["model_frac"] = out["model_tflops"] / (PEAK_F32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS)
+            if args.dtype == "fp32":
+                out["roofline"]["model_note"] = ("algorithmic (direct-convolution) FLOPs of the whole step / time / peak; it may "
+                                                 "exceed 1 because the Winograd layers execute 1/2.25 (forward) or 1/4 (backward) "
+                                                 "of them - `frac` is the utilisation figure")
         if h2d is not None:
             out["h2d_inclusive"] = h2d
         if world == 1 and not args.no_cpu_baseline and not args.eval:

@@ -1048,24 +1048,31 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __
     for (int a = 0; a < 36; ++a) red[g - 1][a][cl] = v[a];
   }
   __syncthreads();
-  if (g != 0 || !ok) return;
+  // group 0 finishes; its nine outputs per (m, c) leave through LDS so that the 64 channels of the chunk are written as one
+  // contiguous run of 576 floats (dw is [m][c][9]: a direct store is nine 36-B-strided store instructions per wave)
+  __shared__ float outs[64 * 9];
+  if (g == 0 && ok) {
 #pragma unroll
-  for (int a = 0; a < 36; ++a) v[a] = ((v[a] + red[0][a][cl]) + red[1][a][cl]) + red[2][a][cl];
-  float gv[3][6];   // G^T v (over the plane row index), per plane column b
+    for (int a = 0; a < 36; ++a) v[a] = ((v[a] + red[0][a][cl]) + red[1][a][cl]) + red[2][a][cl];
+    float gv[3][6];   // G^T v (over the plane row index), per plane column b
 #pragma unroll
-  for (int b = 0; b < 6; ++b) {
-    float o[3];
-    wino4_gt(v + b, 6, o);
-    gv[0][b] = o[0]; gv[1][b] = o[1]; gv[2][b] = o[2];
+    for (int b = 0; b < 6; ++b) {
+      float o[3];
+      wino4_gt(v + b, 6, o);
+      gv[0][b] = o[0]; gv[1][b] = o[1]; gv[2][b] = o[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float o[3];
+      wino4_gt(gv[a], 1, o);
+      outs[cl * 9 + a * 3 + 0] = o[0]; outs[cl * 9 + a * 3 + 1] = o[1]; outs[cl * 9 + a * 3 + 2] = o[2];
+    }
   }
-  float* d = dw + ((long)m * C + c) * 9;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float o[3];
-    wino4_gt(gv[a], 1, o);
-    if (accumulate) { d[a * 3 + 0] += o[0]; d[a * 3 + 1] += o[1]; d[a * 3 + 2] += o[2]; }
-    else { d[a * 3 + 0] = o[0]; d[a * 3 + 1] = o[1]; d[a * 3 + 2] = o[2]; }
-  }
+  __syncthreads();
+  const int c0 = (blockIdx.x % chunks) * 64;
+  const int nout = (C - c0 < 64 ? C - c0 : 64) * 9;
+  float* d = dw + ((long)m * C + c0) * 9;
+  for (int i = threadIdx.x; i < nout; i += 256) d[i] = accumulate ? d[i] + outs[i] : outs[i];
 }
 
 struct WinoWgradParams {
