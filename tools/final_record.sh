@@ -1,0 +1,23 @@
+# usage (on the GPU box): bash tools/final_record.sh  -> gpurun_out/r02_ar_*: full -m gpu suite, smoke, every bench line of the round
+set -e
+T=r02_ar
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest_gpu.txt 2>&1 || { tail -20 gpurun_out/${T}_pytest_gpu.txt; exit 1; }
+tail -2 gpurun_out/${T}_pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.txt 2>&1; tail -2 gpurun_out/${T}_smoke.txt
+python bench.py --h2d > gpurun_out/${T}_bench_f32_b64.jsonl 2>/dev/null
+python bench.py --h2d --dtype bf16 --emb 300 > gpurun_out/${T}_bench_bf16_b64_e300.jsonl 2>/dev/null
+python bench.py --review_net_only --batch 32 > gpurun_out/${T}_bench_umpr_r_b32.jsonl 2>/dev/null
+python bench.py --eval --no-cpu-baseline > gpurun_out/${T}_bench_other.jsonl 2>/dev/null
+python bench.py --eval --dtype bf16 --emb 300 --no-cpu-baseline >> gpurun_out/${T}_bench_other.jsonl 2>/dev/null
+python bench.py --views 4 --batch 32 --no-cpu-baseline >> gpurun_out/${T}_bench_other.jsonl 2>/dev/null
+python bench.py --views 4 --batch 32 --dtype bf16 --emb 300 --no-cpu-baseline >> gpurun_out/${T}_bench_other.jsonl 2>/dev/null
+UMPR_REDUCE_AT_WORLD1=1 python bench.py --no-cpu-baseline >> gpurun_out/${T}_bench_other.jsonl 2>/dev/null
+UMPR_REDUCE_AT_WORLD1=1 python bench.py --dtype bf16 --emb 300 --no-cpu-baseline >> gpurun_out/${T}_bench_other.jsonl 2>/dev/null
+python - <<'P'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r02_ar_bench_*.jsonl")):
+    for l in open(f):
+        l=l.strip()
+        if not l.startswith("{"): continue
+        d=json.loads(l); print(f.split("/")[-1], d["dtype"], d["config"]["workload"][:50], round(d["value"],1), round(d["ms_per_step"],3), round(d["roofline"]["frac"],3), (d.get("cpu_baseline") or {}).get("value"))
+P

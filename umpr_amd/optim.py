@@ -115,8 +115,9 @@ class FusedAdam:
         if self._early is not None and self.reducer is None:
             self.early_step(())
 
-    def early_step(self, handles):
-        """Adam on the classifier-weight slice, on a side stream; `handles`: the slice's pending all-reduces."""
+    def early_step(self, handles, stream=None):
+        """Adam on the classifier-weight slice, on a side stream; `handles`: the slice's pending async all-reduces;
+        `stream`: run it there (the reducer's exchange stream, already ordered behind the slice's in-stream all-reduce)."""
         if self._early is None or self._early_done is not None:
             return
         eb = self.early_bucket()
@@ -126,6 +127,8 @@ class FusedAdam:
         g = self.groups[0]
         _, lo, hi, _ = eb
         dev = g.p.device
+        if stream is not None:
+            self._early_stream = stream
         if self._early_stream is None:
             # Without a gradient exchange the update rides on the library's weight-gradient stream (Adam is HBM-bound, the
             # weight-gradient kernels behind it MFMA-bound): a sixth stream of its own - main, text, weight-gradient, copy

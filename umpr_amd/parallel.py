@@ -113,6 +113,10 @@ class GradReducer:
         self.opt = opt
         self.n_buckets = n_buckets
         self.handles = []
+        self.comm = None               # exchange stream of the in-stream form (early slice + its Adam update)
+        if active() and opt.groups[0].g.is_cuda and self._in_stream(opt.groups[0].g):
+            self.comm = torch.cuda.Stream(opt.groups[0].g.device)   # created before the text / weight-gradient streams: 9.7 vs 10.2 ms
+        self.on_wgrad_stream = False   # a block bucket of this step was enqueued on the weight-gradient stream
         self.early = opt.early_bucket() if hasattr(opt, "early_bucket") else None
         self.fired = False
         self.pending = 0
@@ -122,7 +126,7 @@ class GradReducer:
         # per-VGG-block buckets: the conv weight gradients of block b are exchanged as soon as the feature backward has
         # enqueued that block (model.BLOCK_HOOKS), ordered behind the library's weight-gradient stream - 60 MB that used
         # to wait for the end of the whole backward
-        self.block_slices = self._find_block_slices() if active() else {}
+        self.block_slices = self._find_block_slices() if active() and os.environ.get("UMPR_BLOCK_BUCKETS", "1") != "0" else {}
         self.reduced = []          # (lo, hi) ranges of arena 0 already handed to an all-reduce in this step
         if self.block_slices:
             from . import model as _model
@@ -156,17 +160,44 @@ class GradReducer:
             out[b] = (lo, hi)
         return out
 
+    def _in_stream(self, arena):
+        """Collectives as SYNCHRONOUS ops on a stream of our choice (torch runs a sync NCCL op on the current stream; the
+        host is not blocked) instead of async ops on the process group's internal stream: the early slice travels on one
+        exchange stream that also runs its Adam update, the block buckets on the library's weight-gradient stream right
+        behind the kernels that produce them, the remainder on the caller's stream.
+        Why: every async collective costs three cross-stream event hops (current -> NCCL stream -> waiter) and one more
+        hardware queue, and a 9.5 ms bf16 step is sensitive to that - world-1 rehearsal on one MI355X, where the collectives
+        themselves are no-ops: 12.8 ms async, 9.7-10.2 ms in-stream, 9.5 ms without any exchange; a step with a SINGLE async
+        collective already measured 12.1 ms, with none of the time in a kernel or copy.  The 35 ms fp32 step shows the
+        opposite, smaller effect (35.1 none / 35.5-35.9 async / 37.0-37.5 in-stream: the text kernels get CU slots earlier
+        and push the weight-gradient stream back), so the default follows the arithmetic mode: in-stream for bf16, async for
+        fp32.  UMPR_COMM_ASYNC=1 / 0 forces one form."""
+        if not (arena.is_cuda and dist.get_backend() == "nccl"):
+            return False
+        force = os.environ.get("UMPR_COMM_ASYNC", "")
+        if force in ("0", "1"):
+            return force == "0"
+        return getattr(getattr(self.opt, "model", None), "compute_dtype", "fp32") == "bf16"
+
+    def _wgrad_stream(self, arena):
+        from ._lib import lib
+        ws = lib().fn["umpr_vgg16_wgrad_stream"]() if arena.is_cuda else None
+        return torch.cuda.ExternalStream(ws, device=arena.device) if ws else None
+
     def _on_block(self, block):
         if not active() or block not in self.block_slices:
             return
         import contextlib
-        from ._lib import lib
         lo, hi = self.block_slices[block]
         arena = self.opt.groups[0].g
-        ws = lib().fn["umpr_vgg16_wgrad_stream"]() if arena.is_cuda else None
-        ctx = torch.cuda.stream(torch.cuda.ExternalStream(ws, device=arena.device)) if ws else contextlib.nullcontext()
+        ws = self._wgrad_stream(arena)
+        ctx = torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()
         with ctx:   # the collective is ordered behind the stream the block's weight-gradient kernels were issued on
-            self.handles.append(dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            if self._in_stream(arena):
+                dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM)
+                self.on_wgrad_stream = True
+            else:
+                self.handles.append(dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self.reduced.append((lo, hi))
 
     def _landed(self, _param=None):
@@ -182,6 +213,16 @@ class GradReducer:
         if self.fired:
             return
         arena, lo, hi, _ = self.early
+        if self._in_stream(arena):
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(arena.device)
+            self.comm.wait_stream(torch.cuda.current_stream(arena.device))   # the slice was written on the backward's stream
+            with torch.cuda.stream(self.comm):
+                dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM)
+            self.fired = True
+            if hasattr(self.opt, "early_step"):
+                self.opt.early_step((), stream=self.comm)   # Adam on the slice, same stream: in order behind its all-reduce
+            return
         early = []
         for chunk in torch.chunk(arena[lo:hi], self.n_buckets):
             early.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
@@ -223,9 +264,20 @@ class GradReducer:
             rest += [a for a in arenas if a.data_ptr() != arena.data_ptr()]
         else:
             rest = arenas
+        in_stream = bool(arenas) and self._in_stream(arenas[0])
         for a in rest:
             if a.numel():
-                self.handles.append(dist.all_reduce(a, op=dist.ReduceOp.SUM, async_op=True))
+                if in_stream:
+                    dist.all_reduce(a, op=dist.ReduceOp.SUM)          # on the caller's stream
+                else:
+                    self.handles.append(dist.all_reduce(a, op=dist.ReduceOp.SUM, async_op=True))
+        if in_stream:   # the optimiser step that follows on the caller's stream needs every bucket
+            main = torch.cuda.current_stream(arenas[0].device)
+            if self.comm is not None and self.fired:
+                main.wait_stream(self.comm)
+            if self.on_wgrad_stream:
+                main.wait_stream(self._wgrad_stream(arenas[0]))
+                self.on_wgrad_stream = False
         for h in self.handles:
             h.wait()
         self.handles = []
