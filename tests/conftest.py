@@ -21,11 +21,20 @@ def pytest_configure(config):
 # A process that has initialised the GPU must not fork+exec another GPU program on this pool, so the two-rank job is
 # started here, at session start, BEFORE anything in this process touches the GPU; tests/test_gpu_e2e.py collects it.
 DP_CHECK = {"proc": None, "log": os.path.join(ROOT, "gpurun_out", "dp_check.log")}
-# Same rule for the other settings of UMPR_WINO_F4 (read when the library loads; default 1 = F(4x4,3x3) in backward only):
-# 0 = F(2x2,3x3) everywhere, 2 = F(4x4,3x3) in forward as well.  Each runs four test_conv3x3 cases in one child test run,
-# collected by tests/test_gpu_parity.py::test_conv3x3_winograd_modes.
-WINO_CHECKS = {m: {"proc": None, "log": os.path.join(ROOT, "gpurun_out", f"wino_f4_mode{m}_check.log")} for m in ("0", "2")}
-WINO_CASES = "test_conv3x3 and (2-64-96-56 or 3-40-200-28 or 4-33-65-28 or 1-256-512-28)"
+# Same rule for the jobs of tools/run_gpu_children.py, which run one after the other in ONE child: four test_conv3x3 cases
+# with UMPR_WINO_F4=0 and =2 (read when the library loads; default 1 = F(4x4,3x3) in backward only) and the world-1 RCCL run of
+# the gradient exchange.  Collected by test_conv3x3_winograd_modes / test_gradient_exchange_on_rccl_at_world_one.
+CHILDREN = {"proc": None, "rc": os.path.join(ROOT, "gpurun_out", "gpu_children.rc")}
+
+
+def child_result(name, timeout=900):
+    """(exit code, log text) of one job of tools/run_gpu_children.py; waits for the launcher."""
+    p = CHILDREN["proc"]
+    assert p is not None, "the child jobs were not started (no /dev/kfd, or GPU tests deselected)"
+    p.wait(timeout=timeout)
+    rcs = dict(line.split() for line in open(CHILDREN["rc"]).read().splitlines() if line.strip())
+    assert name in rcs, (name, rcs)
+    return int(rcs[name]), open(os.path.join(ROOT, "gpurun_out", name + ".log")).read()
 
 
 def pytest_sessionstart(session):
@@ -44,16 +53,12 @@ def pytest_sessionstart(session):
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
              "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "tools", "check_dp_gpu.py")],
             stdout=f, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
-    for mode, c in WINO_CHECKS.items():
-        with open(c["log"], "w") as f:
-            c["proc"] = subprocess.Popen(
-                [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-p",
-                 "no:cacheprovider", "-k", WINO_CASES],
-                stdout=f, stderr=subprocess.STDOUT, env=dict(env, UMPR_WINO_F4=mode, UMPR_TEST_CHILD="1"), cwd=ROOT)
+    CHILDREN["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "run_gpu_children.py")], env=env, cwd=ROOT,
+                                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def pytest_sessionfinish(session, exitstatus):
-    for p in [DP_CHECK["proc"]] + [c["proc"] for c in WINO_CHECKS.values()]:
+    for p in (DP_CHECK["proc"], CHILDREN["proc"]):
         if p is not None and p.poll() is None:
             p.kill()
 

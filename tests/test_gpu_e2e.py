@@ -311,6 +311,18 @@ def test_two_rank_data_parallel_on_real_kernels():
     assert "short last batch" in out, out[-3000:]
 
 
+def test_gradient_exchange_on_rccl_at_world_one():
+    """tools/check_exchange_world1.py (a job of tools/run_gpu_children.py): one rank on the RCCL backend runs the early slice, the block
+    buckets, the remainder and the early Adam step with real NCCL calls - the identity at world size 1 - in the async and
+    the in-stream form, fp32 and bf16; parameters and Adam moments after three steps equal the run without exchange
+    bit for bit."""
+    from conftest import child_result
+    rc, out = child_result("exchange_world1_check")
+    assert rc == 0, out[-3000:]
+    assert "world-1 RCCL exchange check passed" in out, out[-3000:]
+    assert out.count("bit-identical") == 4, out[-3000:]
+
+
 def test_umpr_r_full_size_vs_oracle(dev):
     """BASELINE.json configs[0] at its real size: UMPR-R, batch 32, S = L = 20 fully padded (640 sequences per GRU call),
     GloVe-50d - the oracle finishes a step in well under a second, so this is direct parity, not a property."""

@@ -157,13 +157,10 @@ def test_conv3x3(L, dev, N, Cin, Cout, HW):
 def test_conv3x3_winograd_modes(mode):
     """UMPR_WINO_F4=0 keeps every Winograd layer on F(2x2,3x3) (tight 2e-5 absolute bound everywhere); =2 puts the forward
     pass on F(4x4,3x3) as well (bias / ReLU epilogue of wino4_output_kernel).  The switch is read when the library loads,
-    so each setting runs four test_conv3x3 cases in ONE child test run that conftest started before this process touched
-    the GPU."""
-    from conftest import WINO_CHECKS
-    c = WINO_CHECKS[mode]
-    assert c["proc"] is not None, "the child run was not started (no /dev/kfd, or GPU tests deselected)"
-    rc = c["proc"].wait(timeout=900)
-    out = open(c["log"]).read()
+    so each setting runs four test_conv3x3 cases in a child test run (tools/run_gpu_children.py, started by conftest before
+    this process touched the GPU)."""
+    from conftest import child_result
+    rc, out = child_result(f"wino_f4_mode{mode}_check")
     log(f"UMPR_WINO_F4={mode} child: " + (out.strip().splitlines() or ["<no output>"])[-1])
     assert rc == 0, out[-3000:]
     assert "4 passed" in out, out[-3000:]
