@@ -9,7 +9,7 @@
 //                    of a 32-pixel segment are staged once in LDS and serve all nine taps (9 accumulator tiles per
 //                    wave).  Split-K over pixel segments into slabs [split][tap][cout][cin] + deterministic reduce.
 //  dispatch        : umpr_conv3x3_run / umpr_conv3x3_wgrad pick, per layer shape: the first-layer forward kernel
-//                    (Cin <= 3), the Winograd kernels of winograd.hip (56 / 28 / 14 maps with >= 32 channels), the
+//                    (Cin <= 3), the Winograd kernels of winograd.hip (56 / 28 / 14 maps with >= 32 channels; backward of conv2_2), the
 //                    LDS-patch implicit GEMM below (VGG map widths), or the generic gather kernel (any other shape).
 #include "umpr_common.h"
 #include "umpr_internal.h"
@@ -1103,7 +1103,8 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
   const long NP = (long)N * H * W;
   if ((transposed ? wino_bwd_layer(C, M, H, W) : wino_layer(H, W)) && !g_conv_no_wino && !g_conv_force_v1 && wpack && C >= 32 &&
       wpack_floats >= umpr_wino_ws_floats(N, C, M, H, W, transposed)) {
-    // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs; timed under the same family with the direct conv's FLOP count
+    // Winograd (F(2x2,3x3) forward, F(4x4,3x3) data gradient): 2.25x / 4x fewer MFMA FLOPs; timed under the same family with
+    // the direct conv's FLOP count
     UmprProfScope prof(transposed ? UMPR_K_CONV_DGRAD : UMPR_K_CONV_IGEMM, 2.0 * NP * M * C * 9, s);
     return umpr_wino_conv3x3(x, w, transposed, bias, mask, y, N, Cin, Cout, H, W, relu, wpack, wpack_floats, s);
   }
@@ -1192,7 +1193,8 @@ size_t umpr_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
 int umpr_conv3x3_wgrad(const float* gz, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,
                        int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
   if (wgrad_wino_layer(Cin, Cout, H, W) && ws_bytes >= umpr_wino_wgrad_ws_floats(N, Cin, Cout, H, W) * sizeof(float)) {
-    // Winograd F(3x3,2x2): 2.25x fewer MFMA FLOPs; timed under the same family with the direct algorithm's FLOP count
+    // Winograd F(3x3,2x2) / F(3x3,4x4): 2.25x / 4x fewer MFMA FLOPs; timed under the same family with the direct algorithm's
+    // FLOP count
     UmprProfScope prof(UMPR_K_CONV_WGRAD, 2.0 * N * H * W * Cout * Cin * 9, s);
     return umpr_wino_wgrad(gz, x, dw, db, N, Cin, Cout, H, W, accumulate, ws, ws_bytes / sizeof(float), s);
   }

@@ -1,6 +1,6 @@
-// Winograd path for the deep VGG16 layers (56x56, 28x28, 14x14 maps), fp32.
+// Winograd path for the deep VGG16 layers (56x56, 28x28, 14x14 maps; in backward also conv2_2 at 112x112), fp32.
 //
-// Forward and data gradient, F(2x2,3x3):   Y = A^T [ (G g G^T) .* (B^T d B) ] A   per 2x2 output tile / 4x4 input tile
+// Forward, F(2x2,3x3):   Y = A^T [ (G g G^T) .* (B^T d B) ] A   per 2x2 output tile / 4x4 input tile
 //   16 independent GEMMs  M[xi][m][t] = sum_c U[xi][m][c] * V[xi][c][t]  (t = tile index over the batch) replace the
 //   9-tap implicit GEMM: 2.25x fewer MFMA FLOPs.  Kernels per layer call:
 //     wino_weights_kernel      : U = G g G^T (for dgrad on the flipped, channel-transposed kernel), LDS image order
@@ -8,9 +8,14 @@
 //     wino_gemm_dma_kernel     : batched GEMM on v_mfma_f32_32x32x2_f32, operands copied global -> LDS by LDS-DMA
 //                                (wino_gemm_kernel: the same loop staged through registers, UMPR_WINO_DMA=0)
 //     wino_output[_pair]_kernel: M -> y   with the fused epilogue (+bias, ReLU) or (dgrad) * [mask > 0]
-// Weight gradient, F(3x3,2x2): see the second half of this file (wino_dy / wino_wgrad_gemm / wino_wgrad_finish).
-// The shallow layers (224, 112) stay on the direct kernels of conv3x3.hip: there the 16x activation-sized transform
-// traffic costs more than the MFMA time it saves.
+// Data gradient, F(4x4,3x3) where the map is a multiple of 4 (wino4_* kernels, the same GEMM over 36 planes and a quarter of
+//   the tiles: 4x fewer FLOPs, V / M 2.25x instead of 4x the activation), else F(2x2,3x3) as in forward.  The forward pass
+//   keeps the 2x2 tile: the larger tile's rounding (5e-6 of max|y| instead of 3e-7) flips ReLU / pool decisions and moves
+//   the early layers' gradients outside the parity bound; in backward it is a smooth perturbation (UMPR_WINO_F4, below).
+// Weight gradient, F(3x3,2x2) / F(3x3,4x4): see the second half of this file (wino[4]_dy / wino_wgrad_gemm / finish).
+// The 224x224 layers, conv2_1 and the forward pass of conv2_2 stay on the direct kernels of conv3x3.hip: with 64 channels
+// on one side the batched GEMM is HBM-bound on V / M, and in forward the 4x transform traffic of the 2x2 tile costs more
+// than the MFMA time it saves.
 #include "umpr_common.h"
 #include "umpr_internal.h"
 
