@@ -41,6 +41,12 @@ int umpr_gemm_f32(const float* A, long lda, int transA, const float* B, long ldb
  * the way into LDS and runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Set it around a call, clear it after. */
 int umpr_set_gemm_bf16(int on);
 
+/* Inference hint for the fp32 convolution stack (the reference's counterpart is torch.no_grad() around evaluate.py:8-13):
+ * while set on the calling host thread, forward convolutions may use the F(4x4,3x3) Winograd tile that training reserves for
+ * the backward pass - its rounding (5e-6 of max|y|) is irrelevant when no gradient will be taken through the ReLU / pool
+ * decisions of this forward.  Predictions move by ~3e-6.  Set it around umpr_vgg16_features_fwd / umpr_conv3x3_fwd. */
+int umpr_set_conv_inference(int on);
+
 /* ---- K1-K3: embedding lookup + bidirectional packed GRU + the reference's double un-sort ---------------------
  * Replaces nn.Embedding (model.py:262-264) + ImprovedRnn.forward (model.py:12-21) for one review tensor.
  * ids [N*L] int64; emb [vocab][E]; GRU weights in nn.GRU layout (gate order r,z,n): w_ih [192][E], w_hh [192][64],

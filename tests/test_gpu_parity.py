@@ -491,6 +491,24 @@ def _compare_golden(g, model, pred, loss, gname=None):
         check("grad " + k, got.reshape(ref.shape), ref, atol=1e-6, rel_to_max=5e-3, max_bad_frac=1e-3, max_bad=2, rel_l2=6e-3)
 
 
+@pytest.mark.parametrize("name", ["umpr_full_V1_B2", "umpr_full_V4_B2", "umpr_full_V2_P2_B2"])
+def test_umpr_full_golden_inference(dev, name):
+    """The same fixtures under torch.no_grad() (evaluate.py:8-13): VGG16.forward then lets the library use the F(4x4,3x3)
+    tile in the forward pass as well (umpr_set_conv_inference).  Predictions and loss stay within north_star's 1e-4 of the
+    REFERENCE's outputs; the distance to the training-mode forward (2x2 tile) is logged - it is the larger tile's rounding,
+    a few 1e-6."""
+    g, model, batch = _build(name, dev)
+    model.eval()
+    pred_t, loss_t = model(*batch)
+    with torch.no_grad():
+        pred_i, loss_i = model(*batch)
+    torch.cuda.synchronize()
+    log(f"== {name} inference: |pred(no_grad) - pred(grad)| = {float((pred_i - pred_t).abs().max()):.3e}")
+    check("pred (inference)", pred_i, g["prediction"], atol=1e-4)
+    check("loss (inference)", loss_i, g["loss"], atol=1e-4)
+    assert float((pred_i - pred_t).abs().max()) < 5e-5
+
+
 @pytest.mark.parametrize("name", ["umpr_r_B4", "umpr_r_B4_soft", "umpr_r_B3_fullpad"])
 def test_umpr_r_golden(dev, name):
     g, model, batch = _build(name, dev)

@@ -91,6 +91,7 @@ SIGNATURES = {
     "umpr_adam_step": ("ppppldddddldp", "i"),
     "umpr_debug_poison_lds": ("pp", "i"),
     "umpr_set_gemm_bf16": ("i", "i"),
+    "umpr_set_conv_inference": ("i", "i"),
     "umpr_profile_enable": ("i", "i"),
     "umpr_profile_reset": ("", "i"),
     "umpr_profile_read": ("ippp", "i"),

@@ -111,6 +111,7 @@ int umpr_gemm_f32(const float* A, long lda, int transA, const float* B, long ldb
 // its operands to bf16 on the way into LDS and runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (what
 // torch.autocast does to the same nn.GRU / nn.Linear / nn.Conv1d layers).  Hosts set it around a call and clear it after.
 int umpr_set_gemm_bf16(int on) { umpr_gemm_set_b16(on != 0); return 0; }
+int umpr_set_conv_inference(int on) { umpr_wino_set_inference(on != 0); return 0; }
 
 // ------------------------------------------------------------------------------------------------ GRU
 size_t umpr_embed_gru_bidir_ws_bytes(int N, int L, int E) {

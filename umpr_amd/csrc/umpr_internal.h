@@ -70,6 +70,8 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
                      hipStream_t s);
 // winograd.hip
 size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W, int transposed);
+void umpr_wino_set_inference(int on);   // per host thread, see umpr_set_conv_inference
+int umpr_wino_inference();
 int umpr_wino_f4_mode();   // UMPR_WINO_F4: 0 = F(2x2,3x3) only, 1 = F(4x4,3x3) in the backward pass, 2 = forward as well
 size_t umpr_wino_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W);
 int umpr_wino_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int H, int W,

@@ -713,18 +713,31 @@ int umpr_wino_f4_mode() {
   static const int mode = umpr_env_int("UMPR_WINO_F4", 1);   // function-local: also read by conv3x3.hip's initialisers
   return mode;
 }
+// Inference (umpr_set_conv_inference, per host thread): no backward pass will read this forward's ReLU / pool decisions,
+// so the forward pass may take the larger tile as well - predictions move by 3e-6 (bound 1e-4).
+static thread_local int t_wino_infer = 0;
+void umpr_wino_set_inference(int on) { t_wino_infer = on; }
+int umpr_wino_inference() { return t_wino_infer && umpr_wino_f4_mode() >= 1; }
 static inline bool wino_f4_map(int H, int W, int transposed) {
-  return umpr_wino_f4_mode() >= (transposed ? 1 : 2) && (H % 4) == 0 && (W % 4) == 0;
+  const int need = transposed || t_wino_infer ? 1 : 2;
+  return umpr_wino_f4_mode() >= need && (H % 4) == 0 && (W % 4) == 0;
 }
 
 // workspace: U [P][MT*128][S*32] + V [P][S*32][Tpad] + M [P][MT*128][Tpad]  (floats);  P = 16 planes over 2x2 tiles, or
 // 36 planes over 4x4 tiles where the map allows F(4x4,3x3)
 size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W, int transposed) {
-  const bool f4 = wino_f4_map(H, W, transposed);
-  const long T = f4 ? (long)N * (H / 4) * (W / 4) : (long)N * (H / 2) * (W / 2);
-  const long Tpad = wino_tpad(T);
   const long MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
-  return (size_t)(f4 ? 36 : 16) * (MT * WBM * S * WK + S * WK * Tpad + MT * WBM * Tpad) + 64;
+  auto layout = [&](bool f4) {
+    const long T = f4 ? (long)N * (H / 4) * (W / 4) : (long)N * (H / 2) * (W / 2);
+    const long Tpad = wino_tpad(T);
+    return (size_t)(f4 ? 36 : 16) * (MT * WBM * S * WK + S * WK * Tpad + MT * WBM * Tpad) + 64;
+  };
+  const bool map4 = (H % 4) == 0 && (W % 4) == 0;
+  const int mode = umpr_wino_f4_mode();
+  if (!map4 || mode == 0) return layout(false);
+  if (transposed || mode >= 2) return layout(true);
+  const size_t a = layout(false), b = layout(true);   // forward, mode 1: the 2x2 tile, or the 4x4 one in inference
+  return a > b ? a : b;
 }
 
 // Image chunking: V and M (each 4x the activation they transform) are written by one kernel and read back by the next.
