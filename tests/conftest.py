@@ -21,7 +21,7 @@ def pytest_configure(config):
 # A process that has initialised the GPU must not fork+exec another GPU program on this pool, so the two-rank job is
 # started here, at session start, BEFORE anything in this process touches the GPU; tests/test_gpu_e2e.py collects it.
 DP_CHECK = {"proc": None, "log": os.path.join(ROOT, "gpurun_out", "dp_check.log")}
-# Same rule for the jobs of tools/run_gpu_children.py, which run one after the other in ONE child: four test_conv3x3 cases
+# Same rule for the jobs of tools/run_gpu_children.py, which run one after the other in ONE child: six test_conv3x3 cases
 # with UMPR_WINO_F4=0 and =2 (read when the library loads; default 1 = F(4x4,3x3) in backward only) and the world-1 RCCL run of
 # the gradient exchange.  Collected by test_conv3x3_winograd_modes / test_gradient_exchange_on_rccl_at_world_one.
 CHILDREN = {"proc": None, "rc": os.path.join(ROOT, "gpurun_out", "gpu_children.rc")}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Started by tests/conftest.py at session start, BEFORE the test process touches the GPU (a process that has initialised
 the GPU must not fork+exec another GPU program on this pool).  Runs, one after the other so that few processes share the card:
-  * four test_conv3x3 cases with UMPR_WINO_F4=0 and again with =2 (the switch is read when the library loads),
+  * six test_conv3x3 cases with UMPR_WINO_F4=0 and again with =2 (the switch is read when the library loads),
   * tools/check_exchange_world1.py (gradient exchange on the RCCL backend at world size 1).
 This launcher itself never touches the GPU.  Each job writes gpurun_out/<name>.log; the exit codes go to
 gpurun_out/gpu_children.rc as `<name> <rc>` lines."""
@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-WINO_CASES = "test_conv3x3 and (2-64-96-56 or 3-40-200-28 or 4-33-65-28 or 1-256-512-28)"
+WINO_CASES = "test_conv3x3 and (2-64-96-56 or 3-40-200-28 or 4-33-65-28 or 1-256-512-28 or 5-256-256-14 or 2-129-257-14)"
 
 
 def main():

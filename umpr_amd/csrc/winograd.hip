@@ -349,9 +349,11 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
 
 // V[xi][c][t] (c < Cpad),  t = (n*TH + ty)*TW + tx over 4x4 output tiles,  d = x[n][c][4ty-1 .. 4ty+4][4tx-1 .. 4tx+4]
 // One thread per (c, t): per input row one aligned float4 and the two halo scalars; 36 stores, each coalesced over t.
+// EDGE: the map is not a multiple of 4 (14x14): tiles hang over the right / bottom border (zero there), element-wise loads.
+template <bool EDGE>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C,
                                                           int Cpad, int H, int W, long Tpad, long Tw) {
-  const int TH = H / 4, TW = W / 4;
+  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
   const long T = (long)N * TH * TW;
   const long total = (long)Cpad * Tw;
   const long per = (long)Cpad * Tpad;
@@ -376,6 +378,18 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
       const int yy = 4 * ty - 1 + a;
       const bool oky = yy >= 0 && yy < H;
       const float* row = src + (oky ? yy * W : 0) + x0;
+      if (EDGE) {
+        float d[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          const int xx = x0 - 1 + b;
+          const bool ok = oky && xx >= 0 && xx < W;
+          const float v = row[ok ? b - 1 : 0 - x0];   // invalid: element (yy or 0, 0) of the plane, always in range
+          d[b] = ok ? v : 0.f;
+        }
+        wino4_bt(d[0], d[1], d[2], d[3], d[4], d[5], e[a]);
+        continue;
+      }
       const float l = row[okl ? -1 : 0];
       const float4 m = *reinterpret_cast<const float4*>(row);
       const float rr = row[okr ? 4 : 0];
@@ -393,10 +407,11 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
 }
 
 // y[n][m][4ty+i][4tx+j] = epilogue( (A^T M A)[i][j] ): 36 loads coalesced over t, one float4 store per output row
+template <bool EDGE>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, float* __restrict__ y, int N,
                                                            int Mch, int H, int W, long Tpad, int Mpad, int relu) {
-  const int TH = H / 4, TW = W / 4;
+  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
   const long T = (long)N * TH * TW;
   const long total = (long)Mch * T;
   const long per = (long)Mpad * Tpad;
@@ -430,6 +445,18 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
       const long oo = ob + (long)a * W;
+      if (EDGE) {   // outputs past the border are dropped
+        if (4 * ty + a >= H) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (4 * tx + j < W) {
+            float o = v[j];
+            if (mask) o = mask[oo + j] > 0.f ? o : 0.f;
+            y[oo + j] = o;
+          }
+        }
+        continue;
+      }
       if (mask) {
         const float4 mk = *reinterpret_cast<const float4*>(mask + oo);
         v[0] = mk.x > 0.f ? v[0] : 0.f; v[1] = mk.y > 0.f ? v[1] : 0.f;
@@ -718,9 +745,14 @@ int umpr_wino_f4_mode() {
 static thread_local int t_wino_infer = 0;
 void umpr_wino_set_inference(int on) { t_wino_infer = on; }
 int umpr_wino_inference() { return t_wino_infer && umpr_wino_f4_mode() >= 1; }
+// The 4x4 tile pays where 36 planes over ceil(H/4) x ceil(W/4) tiles are less GEMM work than 16 planes over (H/2) x (W/2):
+// always on maps that are a multiple of 4, and on 14x14 (16 tiles of which 3.75 hang over the border: 576 vs 784 plane-tiles).
+static inline bool wino_f4_shape(int H, int W) {
+  return 36L * ((H + 3) / 4) * ((W + 3) / 4) < 16L * (H / 2) * (W / 2);
+}
 static inline bool wino_f4_map(int H, int W, int transposed) {
   const int need = transposed || t_wino_infer ? 1 : 2;
-  return umpr_wino_f4_mode() >= need && (H % 4) == 0 && (W % 4) == 0;
+  return umpr_wino_f4_mode() >= need && wino_f4_shape(H, W);
 }
 
 // workspace: U [P][MT*128][S*32] + V [P][S*32][Tpad] + M [P][MT*128][Tpad]  (floats);  P = 16 planes over 2x2 tiles, or
@@ -728,11 +760,11 @@ static inline bool wino_f4_map(int H, int W, int transposed) {
 size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W, int transposed) {
   const long MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
   auto layout = [&](bool f4) {
-    const long T = f4 ? (long)N * (H / 4) * (W / 4) : (long)N * (H / 2) * (W / 2);
+    const long T = f4 ? (long)N * ((H + 3) / 4) * ((W + 3) / 4) : (long)N * (H / 2) * (W / 2);
     const long Tpad = wino_tpad(T);
     return (size_t)(f4 ? 36 : 16) * (MT * WBM * S * WK + S * WK * Tpad + MT * WBM * Tpad) + 64;
   };
-  const bool map4 = (H % 4) == 0 && (W % 4) == 0;
+  const bool map4 = wino_f4_shape(H, W);
   const int mode = umpr_wino_f4_mode();
   if (!map4 || mode == 0) return layout(false);
   if (transposed || mode >= 2) return layout(true);
@@ -785,7 +817,8 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
   UMPR_REQUIRE(ws_floats >= umpr_wino_ws_floats(N, C, M, H, W, transposed), "winograd: workspace too small");
   const bool f4 = wino_f4_map(H, W, transposed);
   const int planes = f4 ? 36 : 16;
-  const long T = f4 ? (long)N * (H / 4) * (W / 4) : (long)N * (H / 2) * (W / 2);
+  const long T = f4 ? (long)N * ((H + 3) / 4) * ((W + 3) / 4) : (long)N * (H / 2) * (W / 2);
+  const bool edge = f4 && ((H % 4) != 0 || (W % 4) != 0);
   const long Tpad = wino_tpad(T);
   const int MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
   float* U = ws;
@@ -797,8 +830,10 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
     UMPR_LAUNCH_CHECK("wino_weights");
   }
   const long TT = (T + WBN - 1) / WBN;
-  if (f4)
-    wino4_input_kernel<<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
+  if (f4 && edge)
+    wino4_input_kernel<true><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
+  else if (f4)
+    wino4_input_kernel<false><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
   else if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)S * WK * TT * WBN / 2, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
   else
@@ -813,8 +848,10 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
     else wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_gemm");
-  if (f4)
-    wino4_output_kernel<<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
+  if (f4 && edge)
+    wino4_output_kernel<true><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
+  else if (f4)
+    wino4_output_kernel<false><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
   else if ((W / 2) % 2 == 0)
     wino_output_pair_kernel<<<nblk((long)M * T / 2, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
   else
@@ -1001,9 +1038,10 @@ __device__ __forceinline__ void wino4_a(const float g0, const float g1, const fl
   const float s02 = g0 + g2, s13 = g1 + g3, e = g0 + 4.f * g2, f = 2.f * g1 + 8.f * g3;
   o[0] = g0; o[1] = s02 + s13; o[2] = s02 - s13; o[3] = e + f; o[4] = e - f; o[5] = g3;
 }
+template <bool EDGE>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Gy, int N, int Mch, int H,
                                                        int W, long Tpad, long Tw, int Mpad) {
-  const int TH = H / 4, TW = W / 4;
+  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
   const long T = (long)N * TH * TW;
   const long total = (long)Mch * Tw;
   const long per = (long)Mpad * Tpad;
@@ -1023,6 +1061,18 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
     float e[4][6];   // (row of g) A^T
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
+      if (EDGE) {   // gradient rows / columns past the border do not exist: zero
+        const bool oky = 4 * ty + a < H;
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = oky && 4 * tx + j < W;
+          const float v = src[ok ? (long)a * W + j : 0];
+          d[j] = ok ? v : 0.f;
+        }
+        wino4_a(d[0], d[1], d[2], d[3], e[a]);
+        continue;
+      }
       const float4 g = *reinterpret_cast<const float4*>(src + (long)a * W);
       wino4_a(g.x, g.y, g.z, g.w, e[a]);
     }
@@ -1272,9 +1322,11 @@ constexpr int kWinoWgradTargetWgs = 1024;
 struct WinoWgradGeom { long T, Tpad; int MT, CT, Mpad, Cpad, stages, splits, stages_per_split, planes; };
 WinoWgradGeom wino_wgrad_geom(int N, int Cin, int Cout, int H, int W) {
   WinoWgradGeom g;
-  const bool f4 = wino_f4_map(H, W, 1);
+  // padded 14x14 maps stay on F(3x3,2x2): a quarter of the tiles is too short a reduction for the split-K GEMM and the 36-plane
+  // finish (measured 0.367 vs 0.353 ms per layer), while the data gradient gains (0.312 vs 0.351 ms)
+  const bool f4 = wino_f4_map(H, W, 1) && (H % 4) == 0 && (W % 4) == 0;
   g.planes = f4 ? 36 : 16;
-  g.T = f4 ? (long)N * (H / 4) * (W / 4) : (long)N * (H / 2) * (W / 2);
+  g.T = f4 ? (long)N * ((H + 3) / 4) * ((W + 3) / 4) : (long)N * (H / 2) * (W / 2);
   g.Tpad = wino_tpad(g.T);
   g.MT = (Cout + WBM - 1) / WBM; g.CT = (Cin + WBN - 1) / WBN;
   g.Mpad = g.MT * WBM; g.Cpad = g.CT * WBN;
@@ -1323,15 +1375,20 @@ static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db
   const bool f4 = g.planes == 36;
   // rows m >= Cout of Gy are never written: every P element is a dot product of ONE Gy row with ONE V row, so garbage
   // stays in rows of P that the finish kernel does not read.
-  if (f4)
-    wino4_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
+  const bool edge = f4 && ((H % 4) != 0 || (W % 4) != 0);
+  if (f4 && edge)
+    wino4_dy_kernel<true><<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
+  else if (f4)
+    wino4_dy_kernel<false><<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   else if ((W / 2) % 2 == 0)
     wino_dy_pair_kernel<<<nblk((long)Cout * g.Tpad / 2, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   else
     wino_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   UMPR_LAUNCH_CHECK("wino_dy");
-  if (f4)
-    wino4_input_kernel<<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
+  if (f4 && edge)
+    wino4_input_kernel<true><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
+  else if (f4)
+    wino4_input_kernel<false><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
   else if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)g.Cpad * g.Tpad / 2, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
   else
