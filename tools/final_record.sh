@@ -1,6 +1,6 @@
-# usage (on the GPU box): bash tools/final_record.sh  -> gpurun_out/r02_ar_*: full -m gpu suite, smoke, every bench line of the round
+# usage (on the GPU box): bash tools/final_record.sh [tag]  -> gpurun_out/<tag>_*: full -m gpu suite, smoke, every bench line of the round
 set -e
-T=r02_ar
+export T=${1:-r02_final}
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest_gpu.txt 2>&1 || { tail -20 gpurun_out/${T}_pytest_gpu.txt; exit 1; }
 tail -2 gpurun_out/${T}_pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.txt 2>&1; tail -2 gpurun_out/${T}_smoke.txt
@@ -14,8 +14,8 @@ python bench.py --views 4 --batch 32 --dtype bf16 --emb 300 --no-cpu-baseline >>
 UMPR_REDUCE_AT_WORLD1=1 python bench.py --no-cpu-baseline >> gpurun_out/${T}_bench_other.jsonl 2>/dev/null
 UMPR_REDUCE_AT_WORLD1=1 python bench.py --dtype bf16 --emb 300 --no-cpu-baseline >> gpurun_out/${T}_bench_other.jsonl 2>/dev/null
 python - <<'P'
-import json,glob
-for f in sorted(glob.glob("gpurun_out/r02_ar_bench_*.jsonl")):
+import json,glob,os
+for f in sorted(glob.glob("gpurun_out/%s_bench_*.jsonl" % os.environ["T"])):
     for l in open(f):
         l=l.strip()
         if not l.startswith("{"): continue
