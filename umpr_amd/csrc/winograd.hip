@@ -1154,18 +1154,22 @@ struct WinoWgradParams {
   int planes;            // 16: F(3x3,2x2), 36: F(3x3,4x4)
 };
 
-constexpr int WLDT = 130;   // LDS row pitch of the transposed ([k][row]) operand images
+constexpr int WLDK = WK + 4;   // LDS row pitch (floats) of the row-major ([row][k]) operand images: 144-B rows
 
-// grid.x = planes * MT * CT * splits.  Both operands arrive k-contiguous ([row][t]); each thread loads float4 along t and
-// scatters the four values into the [k][row] image the MFMA fragment reads expect (scalar LDS stores, 2-way at most).
+// grid.x = planes * MT * CT * splits.  Both operands arrive k-contiguous ([row][t]) and stay that way in LDS: a thread's float4
+// (four consecutive t of one row) is ONE ds_write_b128, and a lane's MFMA operands for four consecutive k-steps are ONE
+// ds_read_b128.  That works because the MFMA sums over k in any order as long as A and B agree: in every group of 8 tiles the
+// lower half-wave takes t = 0..3 and the upper t = 4..7, one per step (the textbook assignment - t = 2 * step + half - would need
+// stride-2 reads).  144-B rows put the 16 lanes of a b128 phase on 16 distinct 16-B bank groups.  Against the [k][row] image
+// with scalar scatter stores this is a quarter of the LDS instructions; same-box A/B over the four Winograd weight-gradient layer
+// shapes: 1.5-2.8 % faster per layer call (e.g. 512->512@28 0.807 -> 0.787 ms), the step unchanged within noise.
 __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams p) {
-  constexpr int LD = WLDT;
+  constexpr int LD = WLDK;
   constexpr int TM = 2, TN = 2;
-  constexpr int KS = WK / 2;
-  constexpr int NV = 4;
+  constexpr int NG = WK / 8;      // groups of 8 tiles (4 MFMA k-steps) per stage
   constexpr int SFLUSH = 4;
-  __shared__ __attribute__((aligned(16))) float As[2][WK * LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][WK * LD];
+  __shared__ __attribute__((aligned(16))) float As[2][WBM * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WBN * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
@@ -1183,19 +1187,13 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
   const float* pa = p.Gy + ((long)xi * p.Mpad + mt * WBM + urow) * p.Tpad + (long)s_begin * WK + 4 * uq;
   const float* pb = p.V + ((long)xi * p.Cpad + ct * WBN + urow) * p.Tpad + (long)s_begin * WK + 4 * uq;
   const long rstep = 32 * p.Tpad;   // 32 rows per v
-  float* sa = &As[0][(4 * uq) * LD + urow];
-  float* sb = &Bs[0][(4 * uq) * LD + urow];
+  float* sa = &As[0][urow * LD + 4 * uq];
+  float* sb = &Bs[0][urow * LD + 4 * uq];
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
   auto lda = [&](int v, int s) { return *reinterpret_cast<const float4*>(pa + (long)s * WK + v * rstep); };
   auto ldb = [&](int v, int s) { return *reinterpret_cast<const float4*>(pb + (long)s * WK + v * rstep); };
-  auto sta = [&](int v, int buf, const float4& r) {
-    float* d = sa + buf * (WK * LD) + 32 * v;
-    d[0] = r.x; d[LD] = r.y; d[2 * LD] = r.z; d[3 * LD] = r.w;
-  };
-  auto stb = [&](int v, int buf, const float4& r) {
-    float* d = sb + buf * (WK * LD) + 32 * v;
-    d[0] = r.x; d[LD] = r.y; d[2 * LD] = r.z; d[3 * LD] = r.w;
-  };
+  auto sta = [&](int v, int buf, const float4& r) { *reinterpret_cast<float4*>(sa + buf * (WBM * LD) + 32 * v * LD) = r; };
+  auto stb = [&](int v, int buf, const float4& r) { *reinterpret_cast<float4*>(sb + buf * (WBN * LD) + 32 * v * LD) = r; };
   auto piece = [&](int q, int sn, int nbuf) {
     switch (q) {
       case 0: ra0 = lda(0, sn); break;
@@ -1216,6 +1214,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
       default: stb(3, nbuf, rb3); break;
     }
   };
+  auto comp = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
 
   f32x16 acc[TM][TN], tot[TM][TN];
 #pragma unroll
@@ -1239,31 +1238,33 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
     for (int s = s0; s < s1; ++s) {
       const int cur = s & 1;
       const int sn = min(s + 1, ns - 1);
-      const float* as = As[cur] + half * LD + wm * 64 + l31;
-      const float* bs = Bs[cur] + half * LD + wn * 64 + l31;
-      float a[2][TM], bq[2][TN];
+      const float* as = As[cur] + (wm * 64 + l31) * LD + 4 * half;
+      const float* bs = Bs[cur] + (wn * 64 + l31) * LD + 4 * half;
+      float4 a[2][TM], bq[2][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+      for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4*>(as + i * 32 * LD);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bq[0][j] = bs[j * 32];
+      for (int j = 0; j < TN; ++j) bq[0][j] = *reinterpret_cast<const float4*>(bs + j * 32 * LD);
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        const int cb = kk & 1, nb = cb ^ 1;
-        const int k1 = kk + 1;
+      for (int g = 0; g < NG; ++g) {
+        const int cb = g & 1, nb = cb ^ 1;
 #pragma unroll
-        for (int m = 0; m < TM * TN; ++m) {
-          const int i = m / TN, j = m % TN;
-          acc[i][j] = mfma32(a[cb][i], bq[cb][j], acc[i][j]);
-          if (m == 0 && k1 < KS) {
+        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int ii = 0; ii < TM; ++ii) a[nb][ii] = as[2 * k1 * LD + ii * 32];
+          for (int m = 0; m < TM * TN; ++m) {
+            const int i = m / TN, j = m % TN;
+            acc[i][j] = mfma32(comp(a[cb][i], e), comp(bq[cb][j], e), acc[i][j]);
+            if (e == 0 && m == 0 && g + 1 < NG) {
+#pragma unroll
+              for (int ii = 0; ii < TM; ++ii) a[nb][ii] = *reinterpret_cast<const float4*>(as + ii * 32 * LD + 8 * (g + 1));
+            }
+            if (e == 0 && m == 1 && g + 1 < NG) {
+#pragma unroll
+              for (int jj = 0; jj < TN; ++jj) bq[nb][jj] = *reinterpret_cast<const float4*>(bs + jj * 32 * LD + 8 * (g + 1));
+            }
+            if (m == 3) piece(4 * g + e, sn, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          if (m == 1 && k1 < KS) {
-#pragma unroll
-            for (int jj = 0; jj < TN; ++jj) bq[nb][jj] = bs[2 * k1 * LD + jj * 32];
-          }
-          if (m == 3) piece(kk, sn, cur ^ 1);
-          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __syncthreads();
