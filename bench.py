@@ -116,14 +116,18 @@ def spawn_workers(args):
     sys.stdout.flush()
 
 
-def pmc_traffic(bf16=False):
+def pmc_traffic(bf16=False, infer=False):
     """HBM-side bytes per launch of the conv forward family from the committed rocprofv3 --pmc passes
     (profiles/README.md: `tools/pmc_traffic.sh --eval [--dtype bf16 --emb 300]`, forward only so that every conv dispatch
     is a forward launch; FETCH_SIZE doubled per the guide's gfx950 correction), averaged over the 13 forward layer calls of
     a step.  bench.py cannot run the counter passes itself, so the figure is the newest stored measurement, or None."""
     prof = os.path.join(ROOT, "profiles")
     suffix, family = ("_pmc_traffic_bf16_fwd.json", "b16_conv_family") if bf16 else ("_pmc_traffic_fwd.json", "igemm_family")
-    for name in sorted((f for f in os.listdir(prof) if f.endswith(suffix) and ("bf16" in f) == bf16), reverse=True):
+    if infer and not bf16:      # the fp32 inference forward runs the 4x4 Winograd tile: its own stored pass
+        suffix = "_pmc_traffic_infer.json"
+    # newest first: record tags run r02_a .. r02_z, r02_aa .. (longer tag = later)
+    for name in sorted((f for f in os.listdir(prof) if f.endswith(suffix) and ("bf16" in f) == bf16),
+                       key=lambda f: (len(f[:-len(suffix)]), f), reverse=True):
         try:
             d = json.load(open(os.path.join(prof, name)))
             f = d["families"][family]
@@ -328,7 +332,7 @@ def main():
             ms, work, n = fam["wino_gemm"]          # dominant kernel: executed MFMA FLOPs (16 GEMMs of M x C x tiles)
             achieved = per_s(fam["wino_gemm"])
             fwd = fam["conv3x3_fwd"]
-            traffic, traffic_note = (pmc_traffic() if args.batch == 64 and args.views == 1
+            traffic, traffic_note = (pmc_traffic(infer=args.eval) if args.batch == 64 and args.views == 1
                                      else (None, "stored PMC pass is for the batch-64, 1-view workload"))
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note

@@ -2,6 +2,8 @@
 # prescribes), summed per kernel family over one bench run of 2 steps.  Writes gpurun_out/pmc_traffic.json.
 # usage: bash tools/pmc_traffic.sh [extra bench.py args, e.g. --eval: forward only, so that every conv dispatch in the
 # trace is a forward launch (forward, dgrad and the wgrad transforms share kernel names)]
+# `--eval` alone measures the INFERENCE forward (4x4 Winograd tile under no_grad); UMPR_WINO_F4=0 with --eval measures the
+# algorithm of the training forward (2x2 tile).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 EXTRA="$@"
@@ -13,7 +15,7 @@ python3 - <<'PY'
 import csv, glob, json, os, collections
 R = os.environ['GRAFT_REPO_ROOT']
 fam = lambda n: ('b16_conv_family' if any(k in n for k in ('conv_bf16_kernel', 'conv1_bf16_fwd'))
-                 else 'igemm_family' if any(k in n for k in ('conv3x3_igemm', 'wino_', 'pack_weights_kernel', 'conv3x3_fwd', 'conv3x3_dgrad'))
+                 else 'igemm_family' if any(k in n for k in ('conv3x3_igemm', 'wino_', 'wino4_', 'pack_weights_kernel', 'conv3x3_fwd', 'conv3x3_dgrad'))
                  else 'wgrad_family' if ('wgrad' in n) else None)
 out = collections.defaultdict(lambda: collections.defaultdict(float))
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
