@@ -116,7 +116,7 @@ class GradReducer:
         self.comm = None               # exchange stream of the in-stream form (early slice + its Adam update)
         if active() and opt.groups[0].g.is_cuda and self._in_stream(opt.groups[0].g):
             self.comm = torch.cuda.Stream(opt.groups[0].g.device)   # created before the text / weight-gradient streams: 9.7 vs 10.2 ms
-        self.on_wgrad_stream = False   # a block bucket of this step was enqueued on the weight-gradient stream
+        self.comm_used = False         # a collective of this step was enqueued on the exchange stream
         self.early = opt.early_bucket() if hasattr(opt, "early_bucket") else None
         self.fired = False
         self.pending = 0
@@ -163,8 +163,8 @@ class GradReducer:
     def _in_stream(self, arena):
         """Collectives as SYNCHRONOUS ops on a stream of our choice (torch runs a sync NCCL op on the current stream; the
         host is not blocked) instead of async ops on the process group's internal stream: the early slice travels on one
-        exchange stream that also runs its Adam update, the block buckets on the library's weight-gradient stream right
-        behind the kernels that produce them, the remainder on the caller's stream.
+        exchange stream that also runs its Adam update and, behind events of the library's weight-gradient stream, the block
+        buckets; the remainder runs on the caller's stream.
         Why: every async collective costs three cross-stream event hops (current -> NCCL stream -> waiter) and one more
         hardware queue, and a 9.5 ms bf16 step is sensitive to that - world-1 rehearsal on one MI355X, where the collectives
         themselves are no-ops: 12.8 ms async, 9.7-10.2 ms in-stream, 9.5 ms without any exchange; a step with a SINGLE async
@@ -191,12 +191,22 @@ class GradReducer:
         lo, hi = self.block_slices[block]
         arena = self.opt.groups[0].g
         ws = self._wgrad_stream(arena)
-        ctx = torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()
-        with ctx:   # the collective is ordered behind the stream the block's weight-gradient kernels were issued on
-            if self._in_stream(arena):
+        if self._in_stream(arena):
+            # On the exchange stream, behind an event of the weight-gradient stream - NOT on the weight-gradient stream itself:
+            # NCCL runs the collectives of one communicator in issue order, so a bucket issued there would hold that stream
+            # (and every later weight-gradient kernel) until the 494 MB early slice has finished travelling.
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(arena.device)
+            src = ws if ws is not None else torch.cuda.current_stream(arena.device)
+            ev = torch.cuda.Event()
+            ev.record(src)
+            self.comm.wait_event(ev)
+            with torch.cuda.stream(self.comm):
                 dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM)
-                self.on_wgrad_stream = True
-            else:
+            self.comm_used = True
+        else:
+            ctx = torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()
+            with ctx:   # the collective is ordered behind the stream the block's weight-gradient kernels were issued on
                 self.handles.append(dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self.reduced.append((lo, hi))
 
@@ -220,6 +230,7 @@ class GradReducer:
             with torch.cuda.stream(self.comm):
                 dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM)
             self.fired = True
+            self.comm_used = True
             if hasattr(self.opt, "early_step"):
                 self.opt.early_step((), stream=self.comm)   # Adam on the slice, same stream: in order behind its all-reduce
             return
@@ -273,11 +284,9 @@ class GradReducer:
                     self.handles.append(dist.all_reduce(a, op=dist.ReduceOp.SUM, async_op=True))
         if in_stream:   # the optimiser step that follows on the caller's stream needs every bucket
             main = torch.cuda.current_stream(arenas[0].device)
-            if self.comm is not None and self.fired:
+            if self.comm is not None and self.comm_used:
                 main.wait_stream(self.comm)
-            if self.on_wgrad_stream:
-                main.wait_stream(self._wgrad_stream(arenas[0]))
-                self.on_wgrad_stream = False
+                self.comm_used = False
         for h in self.handles:
             h.wait()
         self.handles = []
