@@ -1177,7 +1177,9 @@ static void wgrad_geometry(int W, int* R, int* CW) {
 
 static const bool g_wgrad_wino = umpr_env_on("UMPR_WGRAD_WINO");
 static bool wgrad_wino_layer(int Cin, int Cout, int H, int W) {
-  return g_wgrad_wino && !g_conv_force_v1 && wino_bwd_layer(Cin, Cout, H, W) && Cin >= 32 && Cout >= 32;
+  // conv2_1 (64 -> 128 at 112x112) as well: the weight-gradient GEMM has a 64-wide input-channel tile
+  const bool c21 = wino_112() && H == 112 && W == 112 && Cin >= 64 && Cout >= 128;
+  return g_wgrad_wino && !g_conv_force_v1 && (wino_bwd_layer(Cin, Cout, H, W) || c21) && Cin >= 32 && Cout >= 32;
 }
 
 size_t umpr_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {

@@ -1163,13 +1163,17 @@ constexpr int WLDK = WK + 4;   // LDS row pitch (floats) of the row-major ([row]
 // stride-2 reads).  144-B rows put the 16 lanes of a b128 phase on 16 distinct 16-B bank groups.  Against the [k][row] image
 // with scalar scatter stores this is a quarter of the LDS instructions; same-box A/B over the four Winograd weight-gradient layer
 // shapes: 1.5-2.8 % faster per layer call (e.g. 512->512@28 0.807 -> 0.787 ms), the step unchanged within noise.
+// TN = 2: 128 input channels per workgroup; TN = 1: 64 (layers with 64 input channels - conv2_1 - would leave half of a
+// 128-wide tile multiplying zeros).
+template <int TN>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams p) {
   constexpr int LD = WLDK;
-  constexpr int TM = 2, TN = 2;
+  constexpr int TM = 2;
+  constexpr int BNC = 64 * TN;    // input channels (rows of the V image) per workgroup
   constexpr int NG = WK / 8;      // groups of 8 tiles (4 MFMA k-steps) per stage
   constexpr int SFLUSH = 4;
   __shared__ __attribute__((aligned(16))) float As[2][WBM * LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][WBN * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BNC * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
@@ -1185,7 +1189,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
   // unit u = tid + 256 v: row = u / 8 (0..127), k-quad = u % 8: eight lanes cover one row's 128 contiguous bytes
   const int urow = tid >> 3, uq = tid & 7;
   const float* pa = p.Gy + ((long)xi * p.Mpad + mt * WBM + urow) * p.Tpad + (long)s_begin * WK + 4 * uq;
-  const float* pb = p.V + ((long)xi * p.Cpad + ct * WBN + urow) * p.Tpad + (long)s_begin * WK + 4 * uq;
+  const float* pb = p.V + ((long)xi * p.Cpad + ct * BNC + urow) * p.Tpad + (long)s_begin * WK + 4 * uq;
   const long rstep = 32 * p.Tpad;   // 32 rows per v
   float* sa = &As[0][urow * LD + 4 * uq];
   float* sb = &Bs[0][urow * LD + 4 * uq];
@@ -1193,8 +1197,8 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
   auto lda = [&](int v, int s) { return *reinterpret_cast<const float4*>(pa + (long)s * WK + v * rstep); };
   auto ldb = [&](int v, int s) { return *reinterpret_cast<const float4*>(pb + (long)s * WK + v * rstep); };
   auto sta = [&](int v, int buf, const float4& r) { *reinterpret_cast<float4*>(sa + buf * (WBM * LD) + 32 * v * LD) = r; };
-  auto stb = [&](int v, int buf, const float4& r) { *reinterpret_cast<float4*>(sb + buf * (WBN * LD) + 32 * v * LD) = r; };
-  auto piece = [&](int q, int sn, int nbuf) {
+  auto stb = [&](int v, int buf, const float4& r) { *reinterpret_cast<float4*>(sb + buf * (BNC * LD) + 32 * v * LD) = r; };
+  auto piece = [&](int q, int sn, int nbuf) {   // the V image has 2 * TN row groups of 32: pieces 6, 7, 14, 15 only for TN = 2
     switch (q) {
       case 0: ra0 = lda(0, sn); break;
       case 1: ra1 = lda(1, sn); break;
@@ -1202,16 +1206,16 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
       case 3: ra3 = lda(3, sn); break;
       case 4: rb0 = ldb(0, sn); break;
       case 5: rb1 = ldb(1, sn); break;
-      case 6: rb2 = ldb(2, sn); break;
-      case 7: rb3 = ldb(3, sn); break;
+      case 6: if (TN == 2) rb2 = ldb(2, sn); break;
+      case 7: if (TN == 2) rb3 = ldb(3, sn); break;
       case 8: sta(0, nbuf, ra0); break;
       case 9: sta(1, nbuf, ra1); break;
       case 10: sta(2, nbuf, ra2); break;
       case 11: sta(3, nbuf, ra3); break;
       case 12: stb(0, nbuf, rb0); break;
       case 13: stb(1, nbuf, rb1); break;
-      case 14: stb(2, nbuf, rb2); break;
-      default: stb(3, nbuf, rb3); break;
+      case 14: if (TN == 2) stb(2, nbuf, rb2); break;
+      default: if (TN == 2) stb(3, nbuf, rb3); break;
     }
   };
   auto comp = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
@@ -1239,7 +1243,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
       const int cur = s & 1;
       const int sn = min(s + 1, ns - 1);
       const float* as = As[cur] + (wm * 64 + l31) * LD + 4 * half;
-      const float* bs = Bs[cur] + (wn * 64 + l31) * LD + 4 * half;
+      const float* bs = Bs[cur] + (wn * 32 * TN + l31) * LD + 4 * half;
       float4 a[2][TM], bq[2][TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4*>(as + i * 32 * LD);
@@ -1262,7 +1266,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
 #pragma unroll
               for (int jj = 0; jj < TN; ++jj) bq[nb][jj] = *reinterpret_cast<const float4*>(bs + jj * 32 * LD + 8 * (g + 1));
             }
-            if (m == 3) piece(4 * g + e, sn, cur ^ 1);
+            if (m == TM * TN - 1) piece(4 * g + e, sn, cur ^ 1);   // one staging piece per k-step
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -1274,14 +1278,14 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(WinoWgradParams
 #pragma unroll
       for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
   }
-  float* Pb = p.P + ((((long)split * p.planes + xi) * p.Mpad + mt * WBM) * p.Cpad) + ct * WBN;
+  float* Pb = p.P + ((((long)split * p.planes + xi) * p.Mpad + mt * WBM) * p.Cpad) + ct * BNC;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Pb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Cpad + wn * 64 + j * 32 + l31] = tot[i][j][r];
+        Pb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Cpad + wn * 32 * TN + j * 32 + l31] = tot[i][j][r];
 }
 
 // dw[m][c][3][3] (+)= G^T (sum_split P[split][.][m][c]) G
@@ -1320,7 +1324,7 @@ __global__ void wino_wgrad_finish_kernel(const float* __restrict__ P, int splits
 
 constexpr int kWinoWgradTargetWgs = 1024;
 
-struct WinoWgradGeom { long T, Tpad; int MT, CT, Mpad, Cpad, stages, splits, stages_per_split, planes; };
+struct WinoWgradGeom { long T, Tpad; int MT, CT, Mpad, Cpad, stages, splits, stages_per_split, planes, bnc; };
 WinoWgradGeom wino_wgrad_geom(int N, int Cin, int Cout, int H, int W) {
   WinoWgradGeom g;
   // padded 14x14 maps stay on F(3x3,2x2): a quarter of the tiles is too short a reduction for the split-K GEMM and the 36-plane
@@ -1329,8 +1333,9 @@ WinoWgradGeom wino_wgrad_geom(int N, int Cin, int Cout, int H, int W) {
   g.planes = f4 ? 36 : 16;
   g.T = f4 ? (long)N * ((H + 3) / 4) * ((W + 3) / 4) : (long)N * (H / 2) * (W / 2);
   g.Tpad = wino_tpad(g.T);
-  g.MT = (Cout + WBM - 1) / WBM; g.CT = (Cin + WBN - 1) / WBN;
-  g.Mpad = g.MT * WBM; g.Cpad = g.CT * WBN;
+  g.bnc = Cin <= 64 ? 64 : WBN;   // input-channel tile of the GEMM
+  g.MT = (Cout + WBM - 1) / WBM; g.CT = (Cin + g.bnc - 1) / g.bnc;
+  g.Mpad = g.MT * WBM; g.Cpad = g.CT * g.bnc;
   g.stages = (int)(g.Tpad / WK);
   const int tiles = g.planes * g.MT * g.CT;
   int splits = (kWinoWgradTargetWgs + tiles - 1) / tiles;
@@ -1398,7 +1403,8 @@ static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db
   WinoWgradParams p{Gy, V, P, g.MT, g.CT, g.Mpad, g.Cpad, g.Tpad, g.stages, g.stages_per_split, g.planes};
   {
     UmprProfScope prof(UMPR_K_WINO_WGRAD_GEMM, 2.0 * g.planes * (double)Cout * Cin * g.T, s);
-    wino_wgrad_gemm_kernel<<<(unsigned)(g.planes * g.MT * g.CT * g.splits), 256, 0, s>>>(p);
+    if (g.bnc == 64) wino_wgrad_gemm_kernel<1><<<(unsigned)(g.planes * g.MT * g.CT * g.splits), 256, 0, s>>>(p);
+    else wino_wgrad_gemm_kernel<2><<<(unsigned)(g.planes * g.MT * g.CT * g.splits), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_wgrad_gemm");
   if (f4)
