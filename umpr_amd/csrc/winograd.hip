@@ -1323,6 +1323,7 @@ __global__ void wino_wgrad_finish_kernel(const float* __restrict__ P, int splits
 }
 
 constexpr int kWinoWgradTargetWgs = 1024;
+static const int g_wino_wgrad_rounds = umpr_env_int("UMPR_WINO_WGRAD_ROUNDS", 1);   // 0: the plain 1024-workgroup target
 
 struct WinoWgradGeom { long T, Tpad; int MT, CT, Mpad, Cpad, stages, splits, stages_per_split, planes, bnc; };
 WinoWgradGeom wino_wgrad_geom(int N, int Cin, int Cout, int H, int W) {
@@ -1338,8 +1339,28 @@ WinoWgradGeom wino_wgrad_geom(int N, int Cin, int Cout, int H, int W) {
   g.Mpad = g.MT * WBM; g.Cpad = g.CT * g.bnc;
   g.stages = (int)(g.Tpad / WK);
   const int tiles = g.planes * g.MT * g.CT;
-  int splits = (kWinoWgradTargetWgs + tiles - 1) / tiles;
   const int max_splits = g.stages / 8 > 0 ? g.stages / 8 : 1;   // at least 8 stages (256 tiles) per workgroup
+  // The workgroups of a launch are equally long and 512 fit the chip at a time (2 per CU), so the launch takes
+  // ceil(tiles * splits / 512) rounds: pick the split count that fills its last round best (36 tiles x 29 splits = 1044
+  // workgroups ran 3 rounds for 2.04 rounds of work), the smallest one among those within 3 % of the best, never above the
+  // plain 1024-workgroup target (28x28 layers with 7 splits of 14 stages measured 5-10 % slower than 2-4 splits); below one
+  // round the grid cannot fill the chip anyway and the plain target applies.
+  int splits = (kWinoWgradTargetWgs + tiles - 1) / tiles;
+  if (g_wino_wgrad_rounds && (long)tiles * max_splits >= 512) {
+    double best = 0.0;
+    const int hi = max_splits < splits ? max_splits : splits;   // never more splits than the plain target: short workgroups lose more than a full round wins
+    for (int sp = 1; sp <= hi; ++sp) {
+      const long wgs = (long)tiles * sp;
+      if (wgs < 512) continue;
+      const double eff = (double)wgs / (double)((wgs + 511) / 512 * 512);
+      if (eff > best) best = eff;
+    }
+    for (int sp = 1; sp <= hi; ++sp) {
+      const long wgs = (long)tiles * sp;
+      if (wgs < 512) continue;
+      if ((double)wgs / (double)((wgs + 511) / 512 * 512) >= best - 0.03) { splits = sp; break; }
+    }
+  }
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   g.stages_per_split = (g.stages + splits - 1) / splits;
