@@ -279,6 +279,11 @@ int umpr_bce_head_bwd(const float* att, long ld, const float* w, const float* re
 int umpr_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, long step, double grad_scale, void* stream);
 
+/* ---- evaluate_mse (src/evaluate.py:12-13, `mse_loss(pred, labels, reduction='sum')` accumulated over batches) -----
+ * acc[0] += sum_i (pred[i] - label[i])^2, acc[1] += n; acc = two device doubles the caller zeroed once and reads back
+ * once after the last batch (the reference's `.item()` per batch is a host sync per batch). */
+int umpr_sq_err_accumulate(const float* pred, const float* label, long n, double* acc, void* stream);
+
 /* ---- test aid: fills the LDS of every CU with NaN (LDS is not cleared between kernels, so a kernel that reads LDS
  * it never wrote shows up as NaN in the parity tests instead of passing by luck).  sink: one int of device memory. */
 int umpr_debug_poison_lds(void* sink, void* stream);

@@ -83,3 +83,30 @@ def test_c_abi_reports_errors():
     with pytest.raises(UmprHipError):
         L.call("umpr_maxpool2_fwd", x, y, 64, 27, 27, st)   # odd extent
     assert "maxpool2" in L.last_error()
+
+
+@pytest.mark.gpu
+def test_second_backward_through_the_gru_raises_instead_of_faulting():
+    """the GRU node releases its output buffer after the first backward; a second backward (retain_graph=True) must
+    be a Python error, and the C entry point itself refuses NULL tensors instead of handing them to a kernel."""
+    from umpr_amd._lib import UmprHipError, lib
+    from umpr_amd.model import UMPR, _EmbedGru
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    N, L, E = 5, 6, 50
+    emb = torch.randn(30, E, generator=g).to(dev)
+    ids = torch.randint(3, 30, (N, L), generator=g).to(dev)
+    lens, order = UMPR._host_perm(torch.full((N,), L), dev)
+    w = [((torch.rand(s, generator=g) * 2 - 1) / 8).to(dev).requires_grad_(True)
+         for _ in range(2) for s in ((192, E), (192, 64), (192,), (192,))]
+    out = _EmbedGru.apply(ids, lens, order, emb, 0, *w)
+    out.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already run"):
+        out.sum().backward()
+    Lb = lib()
+    wsb = Lb.size("umpr_embed_gru_bidir_ws_bytes", N, L, E)
+    ws = torch.empty(wsb // 4 + 64, device=dev)
+    gr = [torch.empty_like(t) for t in w]
+    with pytest.raises(UmprHipError, match="NULL"):
+        Lb.call("umpr_embed_gru_bidir_bwd_acc", ids, emb, E, w[1], w[5], lens, order, order, N, L, out.detach(), None, None,
+                *gr, 0, ws, ws.numel() * 4, torch.cuda.current_stream().cuda_stream)

@@ -449,3 +449,257 @@ def test_bf16_training_step_runs_and_tracks_fp32(dev):
         cos = float((d0 * d1).sum() / (d0.norm() * d1.norm() + 1e-30))
         log(f"bf16 train delta {k}: cosine {cos:.4f}")
         assert cos > 0.8, (k, cos)
+
+
+# ------------------------------------------------------------------------------------------------ configs[4] at its own width
+# BASELINE.json configs[4] uses GloVe-300d.  The reference has no bf16 path, so every bound below is against the repo's own
+# fp32 arithmetic / the fp32 oracle: "parity unpinned" for the bf16 mode.  Two references per text test:
+#   "q" - the fp32 oracle fed the bf16-ROUNDED operands of the products the kernels run on the bf16 pipe: isolates the kernels
+#         (what differs is the fp32 summation order and the rounding of intermediate GRADIENT operands): tight;
+#   "f" - the fp32 oracle on the unrounded operands: the stated bf16 bound.
+class _b16_mode:
+    """What UMPR.forward does in bf16 mode: publish the mode to the text Functions of this thread."""
+
+    def __enter__(self):
+        from umpr_amd import model
+        self.m = model
+        self.prev = model._MODE.b16
+        model._MODE.b16 = True
+
+    def __exit__(self, *exc):
+        self.m._MODE.b16 = self.prev
+
+
+def test_embed_gru_bf16_glove300(L, dev):
+    """_EmbedGru with the gather-projection GEMM [sum T x 300] x [300 x 384] on the bf16 pipe (umpr_set_gemm_bf16) at
+    E = 300, N = 130 ragged sequences: forward within 1e-4 of the oracle run on bf16-rounded embedding rows and W_ih (the
+    products of bf16 values are exact in fp32), <= 2e-2 absolute of the unrounded fp32 oracle; weight gradients within 1e-2
+    relative L2 of the rounded-operand oracle (their products round dgx to bf16 as well) and 3e-2 of the fp32 one."""
+    from oracle import umpr_ref as R
+    from umpr_amd.model import UMPR, _EmbedGru
+    N, Lmax, E = 130, 20, 300
+    g = torch.Generator().manual_seed(77)
+    vocab = 400
+    emb = torch.randn(vocab, E, generator=g) * 0.4
+    emb[:3] = 0
+    lengths = torch.randint(1, Lmax + 1, (N,), generator=g)
+    lengths[0] = Lmax
+    ids = torch.randint(3, vocab, (N, Lmax), generator=g)
+    for n in range(N):
+        ids[n, lengths[n]:] = 0
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    shapes = [(192, E), (192, 64), (192,), (192,)]
+    W = {nm + suf: (torch.rand(sh, generator=g) * 2 - 1) / 8 for suf in ("", "_reverse") for nm, sh in zip(names, shapes)}
+    gout = torch.randn(N, Lmax, 128, generator=g)
+    refs = {}
+    for tag in ("f", "q"):
+        P = {"g." + k: (q(v) if (tag == "q" and k.startswith("weight_ih")) else v.clone()).requires_grad_(True) for k, v in W.items()}
+        x = F.embedding(ids, q(emb) if tag == "q" else emb)
+        out = R.improved_rnn(x, lengths, P, "g.", aten=False)
+        out.backward(gout)
+        refs[tag] = (out.detach(), {k: P["g." + k].grad for k in W})
+    lens, order = UMPR._host_perm(lengths, dev)
+    w = [W[n + s].to(dev).requires_grad_(True) for s in ("", "_reverse") for n in names]
+    with _b16_mode():
+        out = _EmbedGru.apply(ids.to(dev), lens, order, emb.to(dev), 0, *w)
+    out.backward(gout.to(dev))
+    eq = float((out.detach().cpu() - refs["q"][0]).abs().max())
+    ef = float((out.detach().cpu() - refs["f"][0]).abs().max())
+    log(f"embed-gru bf16 E300: fwd max|err| vs rounded-operand oracle {eq:.2e}, vs fp32 oracle {ef:.2e}")
+    assert torch.isfinite(out).all() and eq <= 1e-4 and ef <= 2e-2
+    assert ef > 10 * eq, "the bf16 switch did not take effect (the result equals the fp32 product)"
+    for t, k in zip(w, [n + s for s in ("", "_reverse") for n in names]):
+        e_q, e_f = rel_l2(t.grad.cpu(), refs["q"][1][k]), rel_l2(t.grad.cpu(), refs["f"][1][k])
+        log(f"embed-gru bf16 E300 d{k}: relL2 vs rounded-operand oracle {e_q:.2e}, vs fp32 oracle {e_f:.2e}")
+        assert torch.isfinite(t.grad).all() and e_q <= 1e-2 and e_f <= 3e-2, (k, e_q, e_f)
+
+
+@pytest.mark.parametrize("B,S,Lm,m_scale", [(3, 20, 20, 0.05), (4, 20, 20, 1.0)])
+def test_review_head_bf16_mode_vs_fp32_oracle(L, dev, B, S, Lm, m_scale):
+    """_ReviewHead in full bf16 mode (T = G_i M, the S-Net projections and their gradients on the bf16 pipe AND the score
+    contraction in bf16) against the fp32 ORACLE (src/model.py:50-55,71-81,166-168).  Outputs within 3e-2 absolute.  The
+    co-attention gradient is routed through argmax positions, so a bf16 score can pick another (near-tied) maximum: samples
+    whose argmax lists agree with the fp32 kernel path are held to 5e-2 relative L2, the others only to finiteness (ADVICE r2:
+    compare where the routing agrees, and tighten there)."""
+    from oracle import umpr_ref as R
+    from umpr_amd.model import _ReviewHead
+    from umpr_amd.synthetic import make_param_state
+    P = make_param_state(11, 50, 500, 1, False, with_vgg=False, m_scale=m_scale)
+    g = torch.Generator().manual_seed(B * 100 + S + 1)
+    gru_u = (torch.randn(B, S * Lm, 128, generator=g) * 0.5).requires_grad_(True)
+    gru_i = (torch.randn(B, S * Lm, 128, generator=g) * 0.5).requires_grad_(True)
+    pre = "review_net."
+    keys = [pre + "r_net.M", pre + "s_net_u.Ms", pre + "s_net_u.Ws", pre + "s_net_i.Ms", pre + "s_net_i.Ws",
+            pre + "linear_u.weight", pre + "linear_i.weight"]
+    for k in keys:
+        P[k].requires_grad_(True)
+    A = torch.tanh(gru_i @ P[keys[0]] @ gru_u.transpose(-1, -2))
+    colmax, rowmax = A.max(dim=-2), A.max(dim=-1)
+    soft_u, soft_i = torch.softmax(colmax.values, -1), torch.softmax(rowmax.values, -1)
+    atte_u = (gru_u.transpose(-1, -2) @ soft_u.unsqueeze(-1)).squeeze(-1)
+    atte_i = (gru_i.transpose(-1, -2) @ soft_i.unsqueeze(-1)).squeeze(-1)
+    _, su = R.s_net(gru_u, soft_u, Lm, P, pre + "s_net_u.")
+    _, si = R.s_net(gru_i, soft_i, Lm, P, pre + "s_net_i.")
+    ref = torch.tanh(F.linear(torch.cat([atte_u, su], -1), P[keys[5]]) + F.linear(torch.cat([atte_i, si], -1), P[keys[6]]))
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    du, di = gru_u.detach().to(dev).requires_grad_(True), gru_i.detach().to(dev).requires_grad_(True)
+    wd = [P[k].detach().to(dev).requires_grad_(True) for k in keys]
+    with _b16_mode():
+        out = _ReviewHead.apply(du, di, S, Lm, *wd, True)
+    # the argmax lists the kernel routed through are saved tensors 13 (argcol) and 15 (argrow) of the node
+    saved = out.grad_fn.saved_tensors
+    argcol, argrow = saved[13].cpu().long(), saved[15].cpu().long()
+    out.backward(gout.to(dev))
+    e_out = float((out.detach().cpu() - ref.detach()).abs().max())
+    agree = [(bool(torch.equal(argcol[b], colmax.indices[b])) and bool(torch.equal(argrow[b], rowmax.indices[b]))) for b in range(B)]
+    log(f"review head bf16 mode B{B} m{m_scale}: max|dout| vs fp32 oracle {e_out:.2e}; argmax routing agrees for "
+        f"{sum(agree)}/{B} samples")
+    assert torch.isfinite(out).all() and e_out <= 3e-2
+    assert torch.isfinite(du.grad).all() and torch.isfinite(di.grad).all()
+    for b in range(B):
+        if agree[b]:
+            eu, ei = rel_l2(du.grad[b].cpu(), gru_u.grad[b]), rel_l2(di.grad[b].cpu(), gru_i.grad[b])
+            log(f"  sample {b} (same routing): relL2 dGu {eu:.2e} dGi {ei:.2e}")
+            assert eu <= 5e-2 and ei <= 5e-2, (b, eu, ei)
+    for k, t in zip(keys, wd):
+        assert torch.isfinite(t.grad).all(), k
+        e = rel_l2(t.grad.cpu(), P[k].grad)
+        log(f"  d{k}: relL2 vs fp32 oracle {e:.2e} (|g| {float(P[k].grad.norm()):.2e})")
+        if k != keys[0] and float(P[k].grad.norm()) > 1e-6:      # dM sums over the routed entries of every sample
+            assert e <= 5e-2, (k, e)
+
+
+@pytest.mark.parametrize("B,S_ui,L_ui,S,Lm,V", [(3, 5, 20, 20, 20, 1), (4, 3, 11, 6, 9, 4)])
+def test_control_bf16_mode_vs_fp32_oracle(L, dev, B, S_ui, L_ui, S, Lm, V):
+    """_Control in bf16 mode (the C-Net sliding-window GEMM, the control S-Net projection and their gradients on the bf16 pipe)
+    against the fp32 oracle pieces of tests/test_gpu_parity.py::test_control.  The hard gates (view_p < 0.35, view_score vs 0.5,
+    src/model.py:124,192-194) make the outputs discontinuous: entries whose fp32 pre-gate value lies within 2e-2 of a gate are
+    excluded (and counted); everything else within 3e-2 absolute / 5e-2 relative L2."""
+    from oracle import umpr_ref as R
+    from umpr_amd.model import _Control
+    from umpr_amd.synthetic import make_param_state
+    P = make_param_state(13, 50, 500, V, False, with_vgg=False, m_scale=0.3)
+    g = torch.Generator().manual_seed(B * 10 + V + 3)
+    gs = [(torch.randn(B, s * l, 128, generator=g) * 0.7).requires_grad_(True) for s, l in ((S_ui, L_ui), (S, Lm), (S, Lm))]
+    pre = "control_net."
+    keys = [pre + "c_net.cnn.0.weight", pre + "c_net.cnn.0.bias", pre + "c_net.linear.0.weight", pre + "c_net.linear.0.bias",
+            pre + "s_net.Ms", pre + "s_net.Ws", pre + "ss_net.linear.0.weight", pre + "ss_net.linear.0.bias"]
+    for k in keys:
+        P[k].requires_grad_(True)
+    near_gate = []
+
+    def head(x, s, l):
+        cnn_in = x.reshape(B * s, l, -1).transpose(-1, -2)
+        y = F.relu(F.conv1d(cnn_in, P[keys[0]], P[keys[1]], padding=1)).max(dim=-1)[0].view(B, s, -1)
+        vp = torch.sigmoid(F.linear(y, P[keys[2]], P[keys[3]]))
+        near_gate.append(bool(((vp - 0.35).abs() < 2e-2).any()))
+        vp = torch.where(vp < 0.35, torch.zeros_like(vp), vp)
+        return vp, (vp ** 2).sum(-2)
+    vp, c_out = head(gs[0], S_ui, L_ui)
+    _, c_u = head(gs[1], S, Lm)
+    _, c_i = head(gs[2], S, Lm)
+    s_, _ = R.s_net(gs[0], vp, L_ui, P, pre + "s_net.")
+    senti = torch.sigmoid(F.linear(s_, P[keys[6]], P[keys[7]])).expand(-1, -1, V)
+    vs = (senti * vp ** 2).sum(-2) / ((vp ** 2).sum(-2) + 1e-4)
+    q_p = (vs > 0.5).float()
+    q_pos = torch.where(vs < 0.5, torch.zeros_like(vs), 4 * (vs - 0.5) ** 2)
+    q_neg = torch.where(vs > 0.5, torch.zeros_like(vs), 4 * (0.5 - vs) ** 2)
+    refs = [c_u, c_i, c_out * q_p * q_pos, c_out * (1 - q_p) * q_neg]
+    gouts = [torch.randn(r.shape, generator=g) for r in refs]
+    torch.autograd.backward(refs, gouts)
+    gd = [t.detach().to(dev).requires_grad_(True) for t in gs]
+    wd = [P[k].detach().to(dev).requires_grad_(True) for k in keys]
+    with _b16_mode():
+        outs = _Control.apply(gd[0], gd[1], gd[2], (B, S_ui, L_ui, S, Lm), 0.35, *wd)
+    torch.autograd.backward(outs, [t.to(dev) for t in gouts])
+    gated = any(near_gate) or bool(((vs - 0.5).abs() < 2e-2).any())
+    log(f"control bf16 mode V{V}: a pre-gate value within 2e-2 of a hard gate: {gated}")
+    for nm, o, r in zip(("c_u", "c_i", "prefer_pos", "prefer_neg"), outs, refs):
+        e = float((o.detach().cpu() - r.detach()).abs().max())
+        log(f"  {nm}: max|err| vs fp32 oracle {e:.2e} of {float(r.abs().max()):.2e}")
+        assert torch.isfinite(o).all()
+        if not gated:
+            assert e <= 3e-2 * max(1.0, float(r.abs().max())), (nm, e)
+    for i in range(3):
+        e = rel_l2(gd[i].grad.cpu(), gs[i].grad)
+        log(f"  dG{i}: relL2 vs fp32 oracle {e:.2e}")
+        assert torch.isfinite(gd[i].grad).all()
+        if not gated:
+            assert e <= 5e-2, (i, e)
+    for k, t in zip(keys, wd):
+        e = rel_l2(t.grad.cpu(), P[k].grad)
+        log(f"  d{k}: relL2 vs fp32 oracle {e:.2e}")
+        assert torch.isfinite(t.grad).all()
+        if not gated and float(P[k].grad.norm()) > 1e-6:
+            assert e <= 5e-2, (k, e)
+
+
+def test_bf16_eval_mse_within_1e3_of_fp32_glove300_b64(dev):
+    """The MSE criterion of configs[4] at ITS width and per-GPU batch: GloVe-300d-shaped embedding, batches of 64, 1024 samples,
+    same weights in fp32 and bf16 mixed precision (text products, co-attention scores, VGG conv stack and classifier in bf16)."""
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import evaluate_mse
+    P = make_param_state(402, 300, 3000, 1, False, m_scale=0.05)
+    batches = [make_batch(430 + i, 64, 3000, 1) for i in range(16)]
+    m32 = _bf16_model(["unknown"], P, dev, "fp32")
+    with torch.no_grad():
+        mean_pred = float(torch.cat([m32(*b)[0] for b in batches[:4]]).mean())
+    mean_label = float(torch.cat([b[-1] for b in batches]).mean())
+    P["linear_fusion.0.bias"] = P["linear_fusion.0.bias"] + (mean_label - mean_pred)
+    del m32
+    m32 = _bf16_model(["unknown"], P, dev, "fp32")
+    m16 = _bf16_model(["unknown"], P, dev, "bf16")
+    assert m16.embedding.weight.shape[1] == 300 and m16.compute_dtype == "bf16"
+    mse32 = evaluate_mse(m32, batches)
+    mse16 = evaluate_mse(m16, batches)
+    with torch.no_grad():
+        d = torch.cat([m16(*b)[0] - m32(*b)[0] for b in batches[:4]]).cpu()
+    log(f"bf16 eval set E300 B64: MSE fp32 {mse32:.6f} bf16 {mse16:.6f} diff {abs(mse16 - mse32):.2e}; per-sample dpred mean "
+        f"{float(d.mean()):.2e} std {float(d.std()):.2e} max {float(d.abs().max()):.2e}")
+    assert abs(mse16 - mse32) <= 1e-3
+
+
+def test_bf16_trained_model_evaluates_within_1e3_of_fp32_trained(dev):
+    """north_star's "MSE within 1e-3 of fp32" for TRAINING: the same initial weights, the same 32 batches
+    of 16 samples, the same injected dropout masks, 32 Adam steps (main.py:22-37's optimiser; learning rate 1e-4 so that the
+    loss moves) once in fp32 and once in bf16 mixed precision, GloVe-300d-shaped embedding; then evaluate_mse
+    (src/evaluate.py:6-14) of both TRAINED models on a held-out synthetic set of 1024 samples, each in its own arithmetic."""
+    from umpr_amd.config import Config
+    from umpr_amd.model import UMPR
+    from umpr_amd.optim import FusedAdam
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import evaluate_mse, train_step
+    Config.extend({"dtype": "fp32"})
+    E, vocab, steps, Bt = 300, 3000, 32, 16
+    P = make_param_state(501, E, vocab, 1, False, m_scale=0.05)
+    train = [make_batch(510 + i, Bt, vocab, 1) for i in range(steps)]
+    held = [make_batch(560 + i, 64, vocab, 1) for i in range(16)]
+    gm = torch.Generator().manual_seed(9)
+    masks = [(torch.rand(2, Bt, 4096, generator=gm) < 0.5).to(torch.uint8) for _ in range(steps)]
+    res = {}
+    for dt in ("fp32", "bf16"):
+        cfg = Config(argv=[])
+        cfg.views = ["unknown"]
+        cfg.dtype = dt
+        torch.manual_seed(5)
+        m = UMPR(cfg, P["embedding.weight"].numpy())
+        m.load_state_dict(P)
+        m = m.to(dev)
+        mse0 = evaluate_mse(m, held[:4])
+        opt = FusedAdam(m, 1e-4, 1e-3)
+        losses = []
+        for b, mk in zip(train, masks):
+            m.visual_net.vgg16[0].dropout_masks = mk.to(dev)      # both modes see the same masks
+            losses.append(float(train_step(m, opt, b)[1]))
+        m.visual_net.vgg16[0].dropout_masks = None
+        res[dt] = (mse0, losses, evaluate_mse(m, held))
+        opt.close()
+        del m, opt
+        torch.cuda.empty_cache()
+    (a0, la, a1), (b0, lb, b1) = res["fp32"], res["bf16"]
+    log(f"bf16-trained vs fp32-trained: held-out MSE before {a0:.6f} / {b0:.6f}; train loss first {la[0]:.4f} / {lb[0]:.4f} last "
+        f"{la[-1]:.4f} / {lb[-1]:.4f}; held-out MSE after {steps} steps: fp32 {a1:.6f} bf16 {b1:.6f} diff {abs(a1 - b1):.2e}")
+    assert all(np.isfinite(lb)) and all(np.isfinite(la))
+    assert a1 < a0 - 0.05, "the fp32 run did not learn (the criterion needs a learning rate that moves the loss)"
+    assert abs(a1 - b1) <= 1e-3, (a1, b1)

@@ -13,7 +13,10 @@ from conftest import ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
 
-LOG = os.path.join(ROOT, "gpurun_out", "parity.log")
+# the child runs tools/run_gpu_children.py starts (UMPR_WINO_F4 = 0 / 2) log to files of their own: parity.log holds the
+# DEFAULT mode's per-tensor margins only (tools/final_record.sh copies it into profiles/)
+LOG = os.path.join(ROOT, "gpurun_out", "parity.log" if not os.environ.get("UMPR_TEST_CHILD")
+                   else "parity_child_wino_f4_mode%s.log" % os.environ.get("UMPR_WINO_F4", "default"))
 
 
 def log(msg):

@@ -1,8 +1,11 @@
 # usage (on the GPU box): bash tools/final_record.sh [tag]  -> gpurun_out/<tag>_*: full -m gpu suite, smoke, every bench line of the round
 set -e
-export T=${1:-r02_final}
+export T=${1:-r03_final}
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest_gpu.txt 2>&1 || { tail -20 gpurun_out/${T}_pytest_gpu.txt; exit 1; }
 tail -2 gpurun_out/${T}_pytest_gpu.txt
+# the default-mode per-tensor margins of this run (the child runs log elsewhere): kept next to the pass count
+cp gpurun_out/parity.log gpurun_out/${T}_parity_fp32.log 2>/dev/null || true
+cp gpurun_out/parity_bf16.log gpurun_out/${T}_parity_bf16.log 2>/dev/null || true
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.txt 2>&1; tail -2 gpurun_out/${T}_smoke.txt
 python bench.py --h2d > gpurun_out/${T}_bench_f32_b64.jsonl 2>/dev/null
 python bench.py --h2d --dtype bf16 --emb 300 > gpurun_out/${T}_bench_bf16_b64_e300.jsonl 2>/dev/null

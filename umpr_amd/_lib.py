@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -89,6 +90,7 @@ SIGNATURES = {
     "umpr_bce_head_fwd": ("plpppiipppzp", "i"),
     "umpr_bce_head_bwd": ("plpppppiiplpppzp", "i"),
     "umpr_adam_step": ("ppppldddddldp", "i"),
+    "umpr_sq_err_accumulate": ("pplpp", "i"),
     "umpr_debug_poison_lds": ("pp", "i"),
     "umpr_set_gemm_bf16": ("i", "i"),
     "umpr_set_conv_inference": ("i", "i"),
@@ -102,7 +104,12 @@ class UmprHipError(RuntimeError):
     pass
 
 
-GEMM_B16 = False   # set by umpr_amd.model around the text path's calls in bf16 mode (umpr_set_gemm_bf16)
+class _Tls(threading.local):
+    gemm_b16 = False   # set by umpr_amd.model around the text path's calls in bf16 mode (umpr_set_gemm_bf16); per thread,
+                       # like the library's own switch
+
+
+TLS = _Tls()
 
 
 class _Lib:
@@ -132,7 +139,7 @@ class _Lib:
                 conv.append(None)
             else:
                 conv.append(a)
-        if GEMM_B16:
+        if TLS.gemm_b16:
             self.fn["umpr_set_gemm_bf16"](1)
             try:
                 rc = self.fn[name](*conv)

@@ -201,6 +201,7 @@ int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E, co
                                  float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
                                  float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
                                  int accumulate, float* ws, size_t ws_bytes, void* stream) {
+  UMPR_REQUIRE(dout != nullptr && out != nullptr && saved != nullptr, "embed_gru_bwd: dout / out / saved must not be NULL");
   UMPR_REQUIRE(ws_bytes >= umpr_embed_gru_bidir_ws_bytes(N, L, E), "embed_gru_bwd: workspace too small");
   const int tiles = umpr_gru_tiles(N);
   float* dgx = ws;
@@ -1032,6 +1033,12 @@ int umpr_adam_step(float* p, const float* g, float* m, float* v, long n, double 
   const double inv_bc2_sqrt = 1.0 / sqrt(bc2);
   return umpr_adam_impl(p, g, m, v, n, (float)grad_scale, (float)weight_decay, (float)beta1, (float)beta2, (float)eps,
                         (float)step_size, (float)inv_bc2_sqrt, S(stream));
+}
+
+int umpr_sq_err_accumulate(const float* pred, const float* label, long n, double* acc, void* stream) {
+  UMPR_REQUIRE(n >= 0 && acc != nullptr && (n == 0 || (pred != nullptr && label != nullptr)), "sq_err_accumulate: null argument");
+  if (n == 0) return 0;
+  return umpr_sq_err_accumulate_impl(pred, label, n, acc, S(stream));
 }
 
 }  // extern "C"

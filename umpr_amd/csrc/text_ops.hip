@@ -748,6 +748,29 @@ int umpr_dropout_bwd_impl(const float* gy, const uint8_t* mask, const float* a, 
   UMPR_LAUNCH_CHECK("dropout_bwd");
   return 0;
 }
+// evaluate_mse (src/evaluate.py:12-13): acc[0] += sum (pred - label)^2, acc[1] += n.  One workgroup, fixed summation
+// order (thread strides, then a shuffle tree per wave, then the waves in order), float64 accumulator across batches.
+__global__ void __launch_bounds__(256) sq_err_accumulate_kernel(const float* __restrict__ pred, const float* __restrict__ label,
+                                                                long n, double* __restrict__ acc) {
+  __shared__ double part[4];
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const float d = pred[i] - label[i];   // fp32 difference and square like torch's mse_loss(reduction='sum') elements
+    s += (double)(d * d);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    acc[0] += ((part[0] + part[1]) + part[2]) + part[3];
+    acc[1] += (double)n;
+  }
+}
+int umpr_sq_err_accumulate_impl(const float* pred, const float* label, long n, double* acc, hipStream_t s) {
+  sq_err_accumulate_kernel<<<1, 256, 0, s>>>(pred, label, n, acc);
+  UMPR_LAUNCH_CHECK("sq_err_accumulate");
+  return 0;
+}
 int umpr_adam_impl(float* p, const float* g, float* m, float* v, long n, float gscale, float wd, float b1, float b2,
                    float eps, float step_size, float inv_bc2_sqrt, hipStream_t s) {
   adam_kernel<<<nblocks(n, 8192), 256, 0, s>>>(p, g, m, v, n, gscale, wd, b1, b2, eps, step_size, inv_bc2_sqrt);

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 import torch
 from torch import nn
@@ -68,9 +69,19 @@ def _grad_returns(params, dst, direct):
 # --------------------------------------------------------------------------------------------- K1-K3
 # Mixed precision of the text path's GEMM-shaped products (bf16 mode only; UMPR_TEXT_BF16=0 keeps them on the fp32 MFMA
 # kernels): UMPR.forward publishes the mode, every text Function records it at forward time and brackets its library calls
-# with umpr_set_gemm_bf16 (through _lib.GEMM_B16) in forward AND in its backward, whichever thread autograd runs that on.
+# with umpr_set_gemm_bf16 (through _lib.TLS.gemm_b16) in forward AND in its backward, whichever thread autograd runs that on.
 _TEXT_BF16 = os.environ.get("UMPR_TEXT_BF16", "1") != "0"
-_MODE = {"b16": False, "infer": False}   # "infer": the VGG forward in progress runs under torch.no_grad() (VGG16.forward)
+
+
+class _Mode(threading.local):
+    """Per-thread forward state (with the reference's thread-per-replica caller, forward must be re-entrant -
+    no process-global mutable state).  b16: the text Functions of the forward in progress run their products on the bf16
+    pipe; infer: the VGG forward in progress runs under torch.no_grad() (VGG16.forward)."""
+    b16 = False
+    infer = False
+
+
+_MODE = _Mode()
 
 
 class _b16_products:
@@ -78,16 +89,16 @@ class _b16_products:
         self.on = bool(on)
 
     def __enter__(self):
-        self.prev = _lib_mod.GEMM_B16
-        _lib_mod.GEMM_B16 = self.on
+        self.prev = _lib_mod.TLS.gemm_b16
+        _lib_mod.TLS.gemm_b16 = self.on
 
     def __exit__(self, *exc):
-        _lib_mod.GEMM_B16 = self.prev
+        _lib_mod.TLS.gemm_b16 = self.prev
 
 
 def _b16_forward(f):
     def w(ctx, *a):
-        ctx.b16 = _MODE["b16"]
+        ctx.b16 = _MODE.b16
         with _b16_products(ctx.b16):
             return f(ctx, *a)
     return staticmethod(w)
@@ -129,6 +140,9 @@ class _EmbedGru(torch.autograd.Function):
     def backward(ctx, *douts):
         ids, lengths, order, emb, whh_f, whh_r, saved = ctx.saved_tensors
         out = ctx.out
+        if out is None:   # ctx.out is dropped after the first backward (it would otherwise pin the output buffer)
+            raise RuntimeError("_EmbedGru: backward was already run for this forward (the GRU output buffer is released "
+                               "after the first backward; run forward again instead of retain_graph=True)")
         N, L = ids.shape
         E = emb.shape[1]
         dev = ids.device
@@ -302,21 +316,34 @@ class _Control(torch.autograd.Function):
 # Data parallel: callables(block) run on the host each time the feature backward has enqueued one VGG block (4 .. 0) - the
 # gradient reducer starts that block's all-reduce from there (parallel.GradReducer).  Only when the gradients are written
 # in place into the optimiser's arena, i.e. when the slice the hook exchanges really holds this step's values.
-BLOCK_HOOKS = {}     # id(first conv weight Parameter of the VGG16 being differentiated) -> callable(block)
+# The hook is the attribute `_umpr_block_hook` (a weakref.WeakMethod) of the first conv weight Parameter of the VGG16 being
+# differentiated: it lives and dies with that parameter / with the reducer that set it (parallel.GradReducer).
 _BLOCK_CB_TYPE = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
 
 
 def _features_bwd_call(name, direct, params, *args):
-    hook = BLOCK_HOOKS.get(id(params[0])) if params else None
+    ref = getattr(params[0], "_umpr_block_hook", None) if params else None
+    hook = ref() if ref is not None else None
     if hook is not None and all(direct):
+        failed = []
+
         def _cb(block, _user):
-            hook(int(block))
+            # ctypes prints and then DROPS an exception raised inside a C callback: the backward would carry on and this rank
+            # would skip a collective its peers issue.  Keep the first one and re-raise it once the library call returns.
+            if failed:
+                return
+            try:
+                hook(int(block))
+            except BaseException as e:   # noqa: BLE001 - re-raised below
+                failed.append(e)
         cb = _BLOCK_CB_TYPE(_cb)
         lib().call("umpr_vgg16_set_block_callback", ctypes.cast(cb, ctypes.c_void_p), None)
         try:
             lib().call(name, *args)
         finally:
             lib().call("umpr_vgg16_set_block_callback", None, None)
+        if failed:
+            raise failed[0]
     else:
         lib().call(name, *args)
 
@@ -344,7 +371,7 @@ class _VGGFeatures(torch.autograd.Function):
         keep, parr = _ptr_array(params + params[:6])
         # no gradient will be taken through this forward (evaluate.py:8-13 runs under no_grad): the library may then use the
         # F(4x4,3x3) Winograd tile in forward too (umpr_set_conv_inference; +15 % inference throughput, predictions move 3e-6)
-        infer = _MODE["infer"]
+        infer = _MODE.infer
         if infer:
             lib().fn["umpr_set_conv_inference"](1)
         try:
@@ -638,11 +665,11 @@ class VGG16(nn.Module):
         seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
         ps = self.param_list()
         bf16 = self.compute_dtype == "bf16"
-        _MODE["infer"] = not torch.is_grad_enabled()
+        _MODE.infer = not torch.is_grad_enabled()
         try:
             pool5, acts = (_VGGFeaturesBF16 if bf16 else _VGGFeatures).apply(images, *ps[:26])
         finally:
-            _MODE["infer"] = False
+            _MODE.infer = False
         return _VGGClassifier.apply(pool5, acts, self.training, self.dropout_masks, seed, self, bf16, *ps[26:])
 
 
@@ -745,11 +772,11 @@ class UMPR(nn.Module):
                               cn.s_net.Ws, cn.ss_net.linear[0].weight, cn.ss_net.linear[0].bias)
 
     def forward(self, user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels):
-        _MODE["b16"] = self.compute_dtype == "bf16" and _TEXT_BF16
+        _MODE.b16 = self.compute_dtype == "bf16" and _TEXT_BF16
         try:
             return self._forward(user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels)
         finally:
-            _MODE["b16"] = False
+            _MODE.b16 = False
 
     def _forward(self, user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels):
         device = self.embedding.weight.device

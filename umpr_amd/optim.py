@@ -8,19 +8,56 @@ the data-parallel gradient exchange is a handful of large RCCL all-reduces on th
 """
 from __future__ import annotations
 
+import os
+import weakref
+
 import torch
 
 from ._lib import lib, stream_ptr
 
 
-import os
-
 # "1" (default): on; "0": off.
 _EARLY_ADAM = os.environ.get("UMPR_EARLY_ADAM", "1")
 
 
+class WeakCallback:
+    """Entry of a module's ``grad_callbacks``: holds its target method weakly, so an optimiser / reducer that has been
+    dropped (and its ~2 GB of flat arenas) is not kept alive - or called - by the model it was once bound to."""
+
+    def __init__(self, method):
+        self.ref = weakref.WeakMethod(method)
+
+    def __call__(self):
+        m = self.ref()
+        if m is not None:
+            m()
+
+    def targets(self, method):
+        m = self.ref()
+        return m is not None and m == method
+
+
+def add_callback(module, method):
+    module.grad_callbacks[:] = [cb for cb in module.grad_callbacks if not (isinstance(cb, WeakCallback) and cb.ref() is None)]
+    module.grad_callbacks.append(WeakCallback(method))
+
+
+def remove_callback(module, method):
+    module.grad_callbacks[:] = [cb for cb in module.grad_callbacks
+                                if not (isinstance(cb, WeakCallback) and (cb.ref() is None or cb.targets(method)))]
+
+
+def has_callback(module, method):
+    return any(isinstance(cb, WeakCallback) and cb.targets(method) for cb in module.grad_callbacks)
+
+
 def _is_classifier(name):
     return name.startswith("classifier.") or ".classifier." in name
+
+
+def _parallel_active():
+    from . import parallel
+    return parallel.active()
 
 
 class _Group:
@@ -87,9 +124,25 @@ class FusedAdam:
         self._early_done = None     # (lo, hi, event) once the slice has been updated in this step
         self._early_stream = None
         self.reducer = None         # set by parallel.GradReducer: it then calls early_step after launching its all-reduce
+        # one optimiser per model: binding a new one (a resumed run, a second test leg) detaches the old one's callbacks
+        prev = getattr(model, "_umpr_optimizer", None)
+        prev = prev() if prev is not None else None
+        if prev is not None and prev is not self:
+            prev.close()
+        model._umpr_optimizer = weakref.ref(self)
         for m in model.modules():
             if hasattr(m, "grad_callbacks"):
-                m.grad_callbacks.append(self._on_classifier_grads)
+                add_callback(m, self._on_classifier_grads)
+
+    def close(self):
+        """Detach from the model: remove this optimiser's callbacks (and its reducer's).  The parameters stay views of the
+        arenas (they own them from here on); a new FusedAdam on the same model re-points them into its own."""
+        if self.reducer is not None:
+            self.reducer.close()
+        for m in self.model.modules():
+            if hasattr(m, "grad_callbacks"):
+                remove_callback(m, self._on_classifier_grads)
+        self._early = self._early_done = None
 
     def zero_grad(self):
         for g in self.groups:
@@ -112,7 +165,9 @@ class FusedAdam:
         self._early = None
 
     def _on_classifier_grads(self):
-        if self._early is not None and self.reducer is None:
+        # data parallel without a GradReducer (train_step's allreduce_arenas path): the slice is only summed over the ranks
+        # AFTER backward, so an update from here would use this rank's local gradient - never early in that case
+        if self._early is not None and self.reducer is None and not _parallel_active():
             self.early_step(())
 
     def early_step(self, handles, stream=None):

@@ -27,8 +27,10 @@ def active():
     return dist.is_initialized() and (dist.get_world_size() > 1 or _force())
 
 
-def init_distributed(backend=None):
-    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and join the process group."""
+def init_distributed(backend=None, timeout_s=None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and join the process group.
+    `timeout_s`: finite rendezvous / collective timeout (default UMPR_DIST_TIMEOUT_S or 600 s) - a rank whose peer died
+    must not sit in a collective for RCCL's default 10 minutes or the store's 30."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -39,7 +41,11 @@ def init_distributed(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("UMPR_DIST_TIMEOUT_S", "600"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(timeout_s)))
     return rank, local, world
 
 
@@ -122,25 +128,51 @@ class GradReducer:
         self.pending = 0
         self.hooks = []
         if active() and hasattr(opt, "early_step"):
+            prev = getattr(opt, "reducer", None)
+            if prev is not None and prev is not self:
+                prev.close()       # one reducer per optimiser: a stale one must not fire collectives on this arena
             opt.reducer = self     # the optimiser's early classifier update must follow this reducer's all-reduce
         # per-VGG-block buckets: the conv weight gradients of block b are exchanged as soon as the feature backward has
-        # enqueued that block (model.BLOCK_HOOKS), ordered behind the library's weight-gradient stream - 60 MB that used
+        # enqueued that block (model._features_bwd_call), ordered behind the library's weight-gradient stream - 60 MB that used
         # to wait for the end of the whole backward
         self.block_slices = self._find_block_slices() if active() and os.environ.get("UMPR_BLOCK_BUCKETS", "1") != "0" else {}
         self.reduced = []          # (lo, hi) ranges of arena 0 already handed to an all-reduce in this step
+        self._hook_param = None
         if self.block_slices:
-            from . import model as _model
+            import weakref
             g0 = opt.groups[0]
             first = [p for n, p in zip(g0.names, g0.params) if n.endswith(".features.0.weight")]
             if first:
-                _model.BLOCK_HOOKS[id(first[0])] = self._on_block    # keyed by THIS model's first conv weight
+                # the hook lives ON this model's first conv weight (model._features_bwd_call looks it up there), held
+                # weakly: it goes away with the parameter or with this reducer, and no id() can be reused for it
+                first[0]._umpr_block_hook = weakref.WeakMethod(self._on_block)
+                self._hook_param = weakref.ref(first[0])
         if self.early is not None and active():
             self.pending = len(self.early[3])
             self.hooks = [p.register_post_accumulate_grad_hook(self._landed) for p in self.early[3]]
             # gradients written in place (model.py::_grad_targets) pass no AccumulateGrad node: the module says so
+            from .optim import add_callback
             for m in getattr(opt, "model", torch.nn.Module()).modules():
                 if hasattr(m, "grad_callbacks"):
-                    m.grad_callbacks.append(self._written_in_place)
+                    add_callback(m, self._written_in_place)
+
+    def close(self):
+        """Detach from the optimiser / model: hooks and callbacks removed, no collective can be fired from here again."""
+        from .optim import remove_callback
+        for h in self.hooks:
+            h.remove()
+        self.hooks = []
+        for m in getattr(self.opt, "model", torch.nn.Module()).modules():
+            if hasattr(m, "grad_callbacks"):
+                remove_callback(m, self._written_in_place)
+        p = self._hook_param() if getattr(self, "_hook_param", None) is not None else None
+        if p is not None and hasattr(p, "_umpr_block_hook"):
+            del p._umpr_block_hook
+        self._hook_param = None
+        if getattr(self.opt, "reducer", None) is self:
+            self.opt.reducer = None
+        self.early = None
+        self.block_slices = {}
 
     _VGG_BLOCK_CONVS = {0: (0, 2), 1: (5, 7), 2: (10, 12, 14), 3: (17, 19, 21), 4: (24, 26, 28)}
 

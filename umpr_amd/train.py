@@ -11,18 +11,23 @@ from .optim import FusedAdam
 
 
 def evaluate_mse(model, dataloader):
-    """Sum of squared errors over all samples / N (src/evaluate.py:6-14); summed over ranks when distributed."""
-    se, cnt = 0.0, 0
+    """Sum of squared errors over all samples / N (src/evaluate.py:6-14); summed over ranks when distributed.
+    The per-batch sums are accumulated ON THE DEVICE by a library kernel (float64 accumulator, `umpr_sq_err_accumulate`)
+    and read back once at the end: the reference's `.item()` per batch is a host sync per batch."""
+    from ._lib import lib, stream_ptr
+    acc = None
     with torch.no_grad():
         model.eval()
         for batch in dataloader:
             if batch[0].shape[0] == 0:   # this rank's chunk of a short last batch is empty (parallel.shard_bounds)
                 continue
             pred, _ = model(*batch)
-            lab = batch[-1].to(pred.device)
-            se += torch.nn.functional.mse_loss(pred, lab, reduction='sum').item()
-            cnt += len(pred)
+            lab = batch[-1].to(pred.device, non_blocking=True).float().contiguous()
+            if acc is None:
+                acc = torch.zeros(2, dtype=torch.float64, device=pred.device)
+            lib().call("umpr_sq_err_accumulate", pred.contiguous(), lab, pred.numel(), acc, stream_ptr())
     dev = next(model.parameters()).device
+    se, cnt = (acc.tolist() if acc is not None else (0.0, 0.0))
     se, cnt = parallel.allreduce_scalars([se, cnt], dev)
     return se / max(cnt, 1)
 
@@ -53,7 +58,11 @@ def train_step(model, opt: FusedAdam, batch, world=1, reducer=None):
     if loss.dim() > 0:               # main.py:34 takes the mean over DataParallel's per-replica losses; one process per
         loss = loss.mean()           # GPU returns a scalar, whose mean is itself (and costs five tiny kernels)
     opt.zero_grad()
-    opt.arm_early(1.0 / n_active)    # the classifier slice may be updated as soon as its gradients are final
+    if world == 1 or reducer is not None:
+        # the classifier slice may be updated as soon as its gradients are final: at once on one GPU, behind the reducer's
+        # all-reduce of that slice when data parallel.  Without a reducer the exchange only happens after backward
+        # (allreduce_arenas below), so the early update stays off (it would use the local gradient).
+        opt.arm_early(1.0 / n_active)
     loss.backward()
     if world > 1 or reducer is not None:
         if reducer is not None:
