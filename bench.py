@@ -534,7 +534,7 @@ def main():
         if default_line:
             others = {}
             for name, over in OTHER_CONFIGS:
-                w = argparse.Namespace(**{**vars(args), **over, "steps": args.other_steps, "warmup": 2, "h2d": False})
+                w = argparse.Namespace(**{**vars(args), **over, "steps": args.other_steps, "warmup": 3, "h2d": False})
                 try:
                     o, _ = run_workload(w, env)
                 except Exception as e:    # a sub-line must never cost the headline; say what happened
