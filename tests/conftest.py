@@ -22,7 +22,7 @@ def pytest_configure(config):
 # started here, at session start, BEFORE anything in this process touches the GPU; tests/test_gpu_e2e.py collects it.
 DP_CHECK = {"proc": None, "log": os.path.join(ROOT, "gpurun_out", "dp_check.log")}
 # Same rule for the jobs of tools/run_gpu_children.py, which run one after the other in ONE child: six test_conv3x3 cases
-# with UMPR_WINO_F4=0 and =2 (read when the library loads; default 1 = F(4x4,3x3) in backward only) and the world-1 RCCL run of
+# with UMPR_WINO_F4=0 and =1 (read when the library loads; default 2 = F(4x4,3x3) in forward and backward) and the world-1 RCCL run of
 # the gradient exchange.  Collected by test_conv3x3_winograd_modes / test_gradient_exchange_on_rccl_at_world_one.
 CHILDREN = {"proc": None, "rc": os.path.join(ROOT, "gpurun_out", "gpu_children.rc")}
 

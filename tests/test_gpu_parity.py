@@ -130,23 +130,21 @@ def test_conv3x3(L, dev, N, Cin, Cout, HW):
     wtb = wt.numel() * 4
     L.call("umpr_conv3x3_fwd", xd, wd, bd, y, N, Cin, HW, HW, Cout, 1, wt, wtb, st())
     # Layers on the F(4x4,3x3) Winograd tile (56 / 28 / 14 maps - on 14x14 with tiles that hang over the border -, >= 32 reduction
-    # channels; in backward also 128 -> 128 at 112): its transform constants (4, 5, 8, 1/24)
-    # put the fp32 result 4-7e-6 of max|y| from the float64 convolution, where the direct kernels and F(2x2,3x3) sit at
-    # 2-4e-7 (tools/wino43_error.py reproduces both on the CPU).  The stated bound there is 2e-5 of max|y| (= 1e-4 absolute
-    # at these magnitudes, north_star's fp32 tolerance); every other layer keeps 2e-5 absolute.
-    mode = int(os.environ.get("UMPR_WINO_F4", "1"))   # 0: F(2x2,3x3) only, 1: F(4x4,3x3) in backward, 2: forward as well
-    f4_fwd = HW in (56, 28, 14) and Cin >= 32 and mode >= 2
-    f4_bwd = mode >= 1 and ((HW in (56, 28, 14) and Cout >= 32) or (HW == 112 and Cin >= 128 and Cout >= 128))
-    check(f"conv fwd {N},{Cin},{Cout},{HW}", y, y_ref, atol=2e-5, rtol=1e-5, rel_to_max=2e-5 if f4_fwd else None)
+    # channels; in backward also 128 -> 128 at 112).  With the interpolation points (0, +-3/4, +-3/2, inf) of round 3 the fp32
+    # result is 1-2e-6 of max|y| from the float64 convolution (textbook points: 4-8e-6; direct kernels and F(2x2,3x3): 2-4e-7 -
+    # tools/conv_error.py on the GPU, tools/wino43_error.py on the CPU).  The stated bound there is 5e-6 of max|y| on top of the
+    # 2e-5 absolute every other layer keeps.
+    mode = int(os.environ.get("UMPR_WINO_F4", "2"))   # 0: F(2x2,3x3) only, 1: F(4x4,3x3) in backward, 2 (default): forward as well
+    check(f"conv fwd {N},{Cin},{Cout},{HW}", y, y_ref, atol=2e-5, rtol=1e-5, rel_to_max=5e-6 if f4_fwd else None)
     gz = gz_ref.to(dev)
     dx = torch.full(x.shape, float("nan"), device=dev)
     L.call("umpr_conv3x3_bwd_data", gz, wd, None, dx, N, Cin, HW, HW, Cout, wt, wtb, st())
-    check(f"conv dgrad {N},{Cin},{Cout},{HW}", dx, x.grad, atol=2e-5, rtol=1e-4, rel_to_max=2e-5 if f4_bwd else None)
+    check(f"conv dgrad {N},{Cin},{Cout},{HW}", dx, x.grad, atol=2e-5, rtol=1e-4, rel_to_max=5e-6 if f4_bwd else None)
     # masked dgrad (ReLU of the previous layer fused)
     mask_src = torch.randn(x.shape, generator=g)
     L.call("umpr_conv3x3_bwd_data", gz, wd, mask_src.to(dev), dx, N, Cin, HW, HW, Cout, wt, wtb, st())
     check(f"conv dgrad+mask {N},{Cin},{Cout},{HW}", dx, x.grad * (mask_src > 0), atol=2e-5, rtol=1e-4,
-          rel_to_max=2e-5 if f4_bwd else None)
+          rel_to_max=5e-6 if f4_bwd else None)
     dw = torch.full(w.shape, float("nan"), device=dev)
     db = torch.full(b.shape, float("nan"), device=dev)
     wsb = L.size("umpr_conv3x3_bwd_weight_ws_bytes", N, Cin, Cout, HW, HW)
@@ -157,10 +155,10 @@ def test_conv3x3(L, dev, N, Cin, Cout, HW):
     check(f"conv bgrad {N},{Cin},{Cout},{HW}", db, b.grad, atol=1e-4, rtol=1e-4, rel_to_max=1e-5)
 
 
-@pytest.mark.parametrize("mode", ["0", "2"])
+@pytest.mark.parametrize("mode", ["0", "1"])
 def test_conv3x3_winograd_modes(mode):
-    """UMPR_WINO_F4=0 keeps every Winograd layer on F(2x2,3x3) (tight 2e-5 absolute bound everywhere); =2 puts the forward
-    pass on F(4x4,3x3) as well (bias / ReLU epilogue of wino4_output_kernel).  The switch is read when the library loads,
+    """UMPR_WINO_F4=0 keeps every Winograd layer on F(2x2,3x3) (tight 2e-5 absolute bound everywhere); =1 is the round-2
+    arrangement (F(4x4,3x3) in backward only); the default, 2, runs in this process.  The switch is read when the library loads,
     so each setting runs six test_conv3x3 cases in a child test run (tools/run_gpu_children.py, started by conftest before
     this process touched the GPU)."""
     from conftest import child_result
@@ -168,6 +166,39 @@ def test_conv3x3_winograd_modes(mode):
     log(f"UMPR_WINO_F4={mode} child: " + (out.strip().splitlines() or ["<no output>"])[-1])
     assert rc == 0, out[-3000:]
     assert "6 passed" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,HW", [(2, 256, 256, 56), (3, 512, 512, 14), (2, 128, 256, 28)])
+def test_winograd_forward_decisions_are_taken_at_direct_accuracy(L, dev, N, Cin, Cout, HW):
+    """The decision fix-up of the training forward (winograd.hip: wino4_output_kernel<.., FIX> + wino_fixup_kernel): every output
+    whose ReLU decision the 4x4 tile's rounding (1-2e-6 of max|y|) could change is recomputed as a plain dot product.  The bias of
+    every output channel is chosen so that one output of that channel sits within ~1e-7 of zero; together with the naturally small
+    ones that gives a few hundred outputs inside |y| < 3e-6 max|y|.  Stated bounds: those outputs are within 6e-7 max|y| of the
+    float64 convolution (3x the direct kernel's typical error; un-fixed tile outputs are 2-3x further), and NO output whose float64
+    value is at least 4e-7 max|y| away from zero has the wrong sign.  Runs in the default mode only (UMPR_WINO_F4=2)."""
+    if os.environ.get("UMPR_WINO_F4", "2") != "2" or os.environ.get("UMPR_WINO_FIX_KAPPA", "64") == "0":
+        pytest.skip("the training forward is not on the 4x4 tile in this mode")
+    g = torch.Generator().manual_seed(N + Cin + HW)
+    x = torch.relu(torch.randn(N, Cin, HW, HW, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    y0 = F.conv2d(x.double(), w.double(), padding=1)
+    pick = torch.randint(0, N * HW * HW, (Cout,), generator=g)
+    b = torch.stack([-y0[:, m].reshape(-1)[pick[m]] for m in range(Cout)]).float()      # one output per channel lands at ~0
+    y64 = y0 + b.double().view(1, -1, 1, 1)
+    scale = float(y64.abs().max())
+    y = torch.full(y64.shape, float("nan"), device=dev)
+    wt = torch.empty(L.size("umpr_conv3x3_pack_bytes", N, Cin, Cout, HW, HW) // 4, device=dev)
+    L.call("umpr_conv3x3_fwd", x.to(dev), w.to(dev), b.to(dev), y, N, Cin, HW, HW, Cout, 0, wt, wt.numel() * 4, st())
+    yl = y.cpu().double()
+    assert torch.isfinite(yl).all()
+    err = (yl - y64).abs()
+    near = y64.abs() < 3e-6 * scale
+    e_near, e_all = float(err[near].max()) / scale, float(err.max()) / scale
+    wrong = ((yl > 0) != (y64 > 0)) & (y64.abs() >= 4e-7 * scale)
+    log(f"wino fix-up {N},{Cin},{Cout},{HW}: {int(near.sum())} outputs within 3e-6 max|y| of zero: max err {e_near:.2e} of max|y| "
+        f"(all outputs: {e_all:.2e}); wrong signs beyond 4e-7 max|y|: {int(wrong.sum())}")
+    assert int(near.sum()) >= Cout
+    assert e_near <= 6e-7 and e_all <= 5e-6 and int(wrong.sum()) == 0
 
 
 def test_maxpool(L, dev):
@@ -464,6 +495,7 @@ def _compare_golden(g, model, pred, loss, gname=None):
     check("loss", loss, g["loss"], atol=1e-4)
     has_vgg = any("vgg16" in k for k, _ in model.named_parameters())
     g64 = _fp64_yardstick(gname, g) if (has_vgg and gname) else None
+    outside = []
     for k, p in model.named_parameters():
         vggp = "vgg16" in k
         if "grad/" + k in g:
@@ -491,8 +523,10 @@ def _compare_golden(g, model, pred, loss, gname=None):
         scale = float(t64.norm()) + 1e-300
         log(f"grad {k}: L2 |hip-f64|={e_gpu:.3e} |ref32-f64|={e_ref:.3e} |g|={scale:.3e} ratio={e_gpu / max(e_ref, 1e-300):.2f} rel={e_gpu / scale:.2e}")
         assert not torch.isnan(got).any(), k
-        assert e_gpu <= 3.0 * e_ref or e_gpu / scale <= 4e-3, (k, e_gpu, e_ref, e_gpu / scale)
+        if not (e_gpu <= 3.0 * e_ref or e_gpu / scale <= 4e-3):      # every parameter is logged before the test fails
+            outside.append((k, e_gpu, e_ref, e_gpu / scale))
         check("grad " + k, got.reshape(ref.shape), ref, atol=1e-6, rel_to_max=5e-3, max_bad_frac=1e-3, max_bad=2, rel_l2=6e-3)
+    assert not outside, outside
 
 
 @pytest.mark.parametrize("name", ["umpr_full_V1_B2", "umpr_full_V4_B2", "umpr_full_V2_P2_B2"])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Started by tests/conftest.py at session start, BEFORE the test process touches the GPU (a process that has initialised
 the GPU must not fork+exec another GPU program on this pool).  Runs, one after the other so that few processes share the card:
-  * six test_conv3x3 cases with UMPR_WINO_F4=0 and again with =2 (the switch is read when the library loads),
+  * six test_conv3x3 cases with UMPR_WINO_F4=0 and again with =1 (the switch is read when the library loads; default 2),
   * tools/check_exchange_world1.py (gradient exchange on the RCCL backend at world size 1).
 This launcher itself never touches the GPU.  Each job writes gpurun_out/<name>.log; the exit codes go to
 gpurun_out/gpu_children.rc as `<name> <rc>` lines."""
@@ -19,7 +19,7 @@ def main():
     env = dict(os.environ, UMPR_TEST_CHILD="1")
     jobs = [(f"wino_f4_mode{m}_check", dict(env, UMPR_WINO_F4=m),
              [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-p",
-              "no:cacheprovider", "-k", WINO_CASES]) for m in ("0", "2")]
+              "no:cacheprovider", "-k", WINO_CASES]) for m in ("0", "1")]
     jobs.append(("exchange_world1_check", env, [sys.executable, os.path.join(ROOT, "tools", "check_exchange_world1.py")]))
     with open(os.path.join(OUT, "gpu_children.rc"), "w") as rcf:
         for name, e, cmd in jobs:

@@ -1,12 +1,19 @@
 """Rounding error of F(4x4,3x3) against F(2x2,3x3) and the direct fp32 convolution, measured against float64.
-Plain numpy / torch-CPU experiment behind the decision to use the larger tile on the 56x56 and 28x28 layers."""
+Plain numpy / torch-CPU experiment behind the decision to use the larger tile on the 56x56 and 28x28 layers.
+BT4 / G4 / AT4 are the matrices winograd.hip implements since round 3: interpolation points (0, +-3/4, +-3/2, inf)
+(tools/wino_points.py builds them and compares point sets); *_STD are the textbook points (0, +-1, +-2, inf) of rounds 1-2."""
+import os, sys
+from fractions import Fraction as Fr
 import numpy as np, torch, torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from wino_points import cook_toom  # noqa: E402
 
-BT4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+AT4, G4, BT4 = cook_toom((0, Fr(3, 4), Fr(-3, 4), Fr(3, 2), Fr(-3, 2)), 4)
+BT4_STD = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
                 [0, 4, 0, -5, 0, 1]], dtype=np.float64)
-G4 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+G4_STD = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
                [0, 0, 1]], dtype=np.float64)
-AT4 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+AT4_STD = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
 BT2 = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
 G2 = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
 AT2 = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
@@ -39,11 +46,12 @@ def main():
         d32 = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1).numpy()
         y2 = wino(x, w, BT2, G2, AT2, 2)
         y4 = wino(x, w, BT4, G4, AT4, 4)
+        y4s = wino(x, w, BT4_STD, G4_STD, AT4_STD, 4)
         s = np.abs(ref).max()
         rms = np.sqrt((ref ** 2).mean())
-        for name, y in (('direct fp32', d32), ('F(2x2,3x3)', y2), ('F(4x4,3x3)', y4)):
+        for name, y in (('direct fp32', d32), ('F(2x2,3x3)', y2), ('F(4x4,3x3) 3/4,3/2', y4), ('F(4x4,3x3) 1,2', y4s)):
             e = np.abs(y - ref)
-            print(f'C={C} H={H} {name:12s} max err / max|y| = {e.max() / s:.2e}   rms err / rms y = {np.sqrt((e ** 2).mean()) / rms:.2e}')
+            print(f'C={C} H={H} {name:20s} max err / max|y| = {e.max() / s:.2e}   rms err / rms y = {np.sqrt((e ** 2).mean()) / rms:.2e}')
 
 
 if __name__ == '__main__':

@@ -286,26 +286,78 @@ __global__ void wino_output_pair_kernel(const float* __restrict__ Mx, const floa
 // ---------------------------------------------------------------------------------------------------------------------
 // F(4x4,3x3): 6x6 input tile -> 4x4 outputs, 36 planes.  4x fewer multiplies than the direct convolution (F(2x2,3x3):
 // 2.25x) and V / M are 2.25x the activation they transform instead of 4x - both the GEMM and the HBM-bound transforms
-// shrink.  Used where the map is a multiple of 4 (56x56, 28x28).  The price is rounding: the transform matrices hold
-// 4, 5, 8 and 1/24, so the fp32 result is 4-7e-6 of max|y| from the float64 convolution where the direct kernel and
-// F(2x2,3x3) are at 2-4e-7 (tools/wino43_error.py) - inside the 2e-5 per-layer bound of test_conv3x3.
-//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// shrink.  Used where 36 planes over ceil(H/4) x ceil(W/4) tiles are less work than 16 planes over (H/2) x (W/2).
+// Interpolation points (0, +-a, +-b, inf), Cook-Toom construction (tools/wino_points.py):
+//   A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]
+//   B^T = [a^2b^2 0 -(a^2+b^2) 0 1 0; 0 -ab^2 -b^2 a 1 0; 0 ab^2 -b^2 -a 1 0; 0 -a^2b -a^2 b 1 0; 0 a^2b -a^2 -b 1 0;
+//          0 a^2b^2 0 -(a^2+b^2) 0 1]
+//   G   = [1/(a^2b^2) 0 0; ca(1 a a^2); ca(1 -a a^2); cb(1 b b^2); cb(1 -b b^2); 0 0 1],  ca = 1/(2a^2(a^2-b^2)), cb = 1/(2b^2(b^2-a^2))
+// The price of the larger tile is rounding, and the points set it.  The textbook points (a, b) = (1, 2) (constants 4, 5, 8,
+// 1/24) put the fp32 result 3-4e-6 of max|y| (rms 1.1e-6) from the float64 convolution where the direct kernel and
+// F(2x2,3x3) are at 2e-7: enough to flip ~15x more ReLU / max-pool decisions than the direct kernel in a TRAINING forward
+// pass, which moved the first layers' gradients outside the golden-fixture bound (round 2: forward stayed on the 2x2 tile).
+// Round 3: (a, b) = (3/4, 3/2) - every constant of B^T and A^T is dyadic (exact in fp32), the Vandermonde rows are better
+// balanced - measures max 0.8-1.2e-6, rms 5.6e-7 on the same experiment (tools/wino_points.py), and the CPU simulation of the
+// golden-fixture criterion (tools/wino_flip_sim.py) puts it level with F(2x2,3x3) (first conv's gradient 1.2e-3 from the
+// float64 run vs 1.1e-3; textbook points 2.8e-3).  UMPR_WINO_POINTS=0 selects the textbook points (A/B runs).
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wino4_bt(const float d0, const float d1, const float d2, const float d3, const float d4,
-                                         const float d5, float* __restrict__ o) {
-  o[0] = 4.f * d0 - 5.f * d2 + d4;
-  o[1] = -4.f * (d1 + d2) + d3 + d4;
-  o[2] = 4.f * (d1 - d2) - d3 + d4;
-  o[3] = 2.f * (d3 - d1) - d2 + d4;
-  o[4] = 2.f * (d1 - d3) - d2 + d4;
-  o[5] = 4.f * d1 - 5.f * d3 + d5;
+struct Wino4C {
+  float a, b, a2, b2, a3, b3;   // A^T
+  float p, sm, ab2, a2b;        // B^T: p = a^2 b^2, sm = a^2 + b^2
+  float g0, ca, cb;             // G: 1 / (a^2 b^2), ca, cb
+};
+static Wino4C wino4_consts() {
+  static const int textbook = umpr_env_int("UMPR_WINO_POINTS", 1) == 0;
+  const double a = textbook ? 1.0 : 0.75, b = textbook ? 2.0 : 1.5;
+  Wino4C c;
+  c.a = (float)a; c.b = (float)b; c.a2 = (float)(a * a); c.b2 = (float)(b * b); c.a3 = (float)(a * a * a); c.b3 = (float)(b * b * b);
+  c.p = (float)(a * a * b * b); c.sm = (float)(a * a + b * b); c.ab2 = (float)(a * b * b); c.a2b = (float)(a * a * b);
+  c.g0 = (float)(1.0 / (a * a * b * b));
+  c.ca = (float)(1.0 / (2.0 * a * a * (a * a - b * b)));
+  c.cb = (float)(1.0 / (2.0 * b * b * (b * b - a * a)));
+  return c;
+}
+__device__ __forceinline__ void wino4_bt(const Wino4C& c, const float d0, const float d1, const float d2, const float d3,
+                                         const float d4, const float d5, float* __restrict__ o) {
+  const float ea = d4 - c.b2 * d2, oa = c.a * d3 - c.ab2 * d1;    // rows +-a: even and odd part
+  const float eb = d4 - c.a2 * d2, ob = c.b * d3 - c.a2b * d1;    // rows +-b
+  o[0] = c.p * d0 - c.sm * d2 + d4;
+  o[1] = ea + oa;
+  o[2] = ea - oa;
+  o[3] = eb + ob;
+  o[4] = eb - ob;
+  o[5] = c.p * d1 - c.sm * d3 + d5;
+}
+// G g for one column of three filter taps
+__device__ __forceinline__ void wino4_g(const Wino4C& c, const float g0, const float g1, const float g2, float* __restrict__ o) {
+  const float ea = g0 + c.a2 * g2, eb = g0 + c.b2 * g2;
+  o[0] = c.g0 * g0;
+  o[1] = c.ca * (ea + c.a * g1);
+  o[2] = c.ca * (ea - c.a * g1);
+  o[3] = c.cb * (eb + c.b * g1);
+  o[4] = c.cb * (eb - c.b * g1);
+  o[5] = g2;
+}
+// A^T q for six plane values
+__device__ __forceinline__ void wino4_at(const Wino4C& c, const float* __restrict__ q, float* __restrict__ y) {
+  const float s12 = q[1] + q[2], d12 = q[1] - q[2], s34 = q[3] + q[4], d34 = q[3] - q[4];
+  y[0] = q[0] + s12 + s34;
+  y[1] = c.a * d12 + c.b * d34;
+  y[2] = c.a2 * s12 + c.b2 * s34;
+  y[3] = c.a3 * d12 + c.b3 * d34 + q[5];
+}
+// |A^T| q for six NON-NEGATIVE values: the magnitude that feeds each output (decision fix-up below)
+__device__ __forceinline__ void wino4_at_abs(const Wino4C& c, const float* __restrict__ q, float* __restrict__ y) {
+  const float s12 = q[1] + q[2], s34 = q[3] + q[4];
+  y[0] = q[0] + s12 + s34;
+  y[1] = c.a * s12 + c.b * s34;
+  y[2] = c.a2 * s12 + c.b2 * s34;
+  y[3] = c.a3 * s12 + c.b3 * s34 + q[5];
 }
 
 // U[xi][mt][s][k][m_local], xi = 6a + b: the image order of wino_weights_kernel with 36 planes
 __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int M, int C, int CinW,
-                                     int transposed) {
+                                     int transposed, Wino4C wc) {
   const int MT = (M + WBM - 1) / WBM, S = (C + WK - 1) / WK;
   const long total = (long)MT * WBM * S * WK;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -325,24 +377,18 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
     float gg[6][3];   // G g
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
-      gg[0][j] = 0.25f * g0;
-      gg[1][j] = (-1.f / 6.f) * (g0 + g1 + g2);
-      gg[2][j] = (-1.f / 6.f) * (g0 - g1 + g2);
-      gg[3][j] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-      gg[4][j] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-      gg[5][j] = g2;
+      float o[6];
+      wino4_g(wc, g[j], g[3 + j], g[6 + j], o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) gg[a][j] = o[a];
     }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      const float g0 = gg[a][0], g1 = gg[a][1], g2 = gg[a][2];
+      float o[6];
+      wino4_g(wc, gg[a][0], gg[a][1], gg[a][2], o);
       float* dst = U + (long)(a * 6) * total + i;
-      dst[0] = 0.25f * g0;
-      dst[total] = (-1.f / 6.f) * (g0 + g1 + g2);
-      dst[2 * total] = (-1.f / 6.f) * (g0 - g1 + g2);
-      dst[3 * total] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-      dst[4 * total] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-      dst[5 * total] = g2;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) dst[(long)b * total] = o[b];
     }
   }
 }
@@ -352,7 +398,9 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
 // EDGE: the map is not a multiple of 4 (14x14): tiles hang over the right / bottom border (zero there), element-wise loads.
 template <bool EDGE>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C,
-                                                          int Cpad, int H, int W, long Tpad, long Tw) {
+                                                          int Cpad, int H, int W, long Tpad, long Tw, Wino4C wc,
+                                                          unsigned int* __restrict__ zero) {
+  if (zero && blockIdx.x == 0 && threadIdx.x == 0) *zero = 0u;   // the fix-up list counter of this pass (see WinoFix)
   const int TH = (H + 3) / 4, TW = (W + 3) / 4;
   const long T = (long)N * TH * TW;
   const long total = (long)Cpad * Tw;
@@ -387,30 +435,49 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
           const float v = row[ok ? b - 1 : 0 - x0];   // invalid: element (yy or 0, 0) of the plane, always in range
           d[b] = ok ? v : 0.f;
         }
-        wino4_bt(d[0], d[1], d[2], d[3], d[4], d[5], e[a]);
+        wino4_bt(wc, d[0], d[1], d[2], d[3], d[4], d[5], e[a]);
         continue;
       }
       const float l = row[okl ? -1 : 0];
       const float4 m = *reinterpret_cast<const float4*>(row);
       const float rr = row[okr ? 4 : 0];
-      wino4_bt(oky && okl ? l : 0.f, oky ? m.x : 0.f, oky ? m.y : 0.f, oky ? m.z : 0.f, oky ? m.w : 0.f,
+      wino4_bt(wc, oky && okl ? l : 0.f, oky ? m.x : 0.f, oky ? m.y : 0.f, oky ? m.z : 0.f, oky ? m.w : 0.f,
                oky && okr ? rr : 0.f, e[a]);
     }
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       float o[6];
-      wino4_bt(e[0][b], e[1][b], e[2][b], e[3][b], e[4][b], e[5][b], o);
+      wino4_bt(wc, e[0][b], e[1][b], e[2][b], e[3][b], e[4][b], e[5][b], o);
 #pragma unroll
       for (int a = 0; a < 6; ++a) dst[(long)(a * 6 + b) * per] = o[a];
     }
   }
 }
 
+// Decision fix-up of the TRAINING forward (round 3).  The 4x4 tile's fp32 result carries ~9e-7 (rms, of rms y) of rounding
+// where the direct kernel carries 1.7e-7 (tools/conv_error.py).  As a perturbation of the values that is harmless; but every
+// ReLU / max-pool DECISION of the forward pass is replayed by the backward pass, and one decision that lands on the other side
+// of the float64 one moves the gradients of all earlier layers by ~1e-3 relative L2 (tools/relu_flip_experiment.py) - five
+// times the noise means five times the flipped decisions, which is what kept the training forward on the 2x2 tile in round 2.
+// So the decisions are taken at the direct kernel's accuracy instead: the output transform flags every output whose decision
+// the tile's rounding could change - |y| < tau (ReLU), or a 2x2 pool window whose leader is less than tau ahead of the
+// runner-up - with tau = kappa * 2^-24 * S,  S = sum_ab |A^T_ia| |A^T_jb| |M_ab| the magnitude that fed that output (local and
+// scale-free: no pass over the tensor, no global maximum), and appends its index to a list; wino_fixup_kernel then recomputes
+// the listed outputs (a few per 100 000) as plain 9 C-term dot products, one wave each.  The list order depends on the
+// atomics, the values do not: every listed element is recomputed independently in a fixed summation order.
+struct WinoFix {
+  unsigned int* count;   // zeroed by the input-transform kernel of the same pass
+  unsigned int* list;    // output element indices
+  unsigned int cap;
+  float kappa_eps;       // kappa * 2^-24
+};
+
 // y[n][m][4ty+i][4tx+j] = epilogue( (A^T M A)[i][j] ): 36 loads coalesced over t, one float4 store per output row
-template <bool EDGE>
+template <bool EDGE, bool FIX>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, float* __restrict__ y, int N,
-                                                           int Mch, int H, int W, long Tpad, int Mpad, int relu) {
+                                                           int Mch, int H, int W, long Tpad, int Mpad, int relu, Wino4C wc,
+                                                           WinoFix fx) {
   const int TH = (H + 3) / 4, TW = (W + 3) / 4;
   const long T = (long)N * TH * TW;
   const long total = (long)Mch * T;
@@ -423,30 +490,44 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     const int ty = (int)(r % TH), n = (int)(r / TH);
     const float* src = Mx + (long)m * Tpad + t;
     float am[4][6];   // A^T M, accumulated plane row by plane row
+    float as[FIX ? 4 : 1][6];   // |A^T| |M|
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       float q[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) q[a] = src[(long)(a * 6 + b) * per];
-      const float s12 = q[1] + q[2], d12 = q[1] - q[2], s34 = q[3] + q[4], d34 = q[3] - q[4];
-      am[0][b] = q[0] + s12 + s34;
-      am[1][b] = d12 + 2.f * d34;
-      am[2][b] = s12 + 4.f * s34;
-      am[3][b] = d12 + 8.f * d34 + q[5];
+      float o[4];
+      wino4_at(wc, q, o);
+      am[0][b] = o[0]; am[1][b] = o[1]; am[2][b] = o[2]; am[3][b] = o[3];
+      if (FIX) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) q[a] = fabsf(q[a]);
+        wino4_at_abs(wc, q, o);
+        as[0][b] = o[0]; as[1][b] = o[1]; as[2][b] = o[2]; as[3][b] = o[3];
+      }
     }
     const float bv = bias ? bias[m] : 0.f;
     const long ob = (((long)n * Mch + m) * H + 4 * ty) * W + 4 * tx;
+    float vv[FIX ? 4 : 1][4], tau[FIX ? 4 : 1][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      const float s12 = am[a][1] + am[a][2], d12 = am[a][1] - am[a][2], s34 = am[a][3] + am[a][4], d34 = am[a][3] - am[a][4];
-      float v[4] = {am[a][0] + s12 + s34 + bv, d12 + 2.f * d34 + bv, s12 + 4.f * s34 + bv, d12 + 8.f * d34 + am[a][5] + bv};
+      float v[4];
+      wino4_at(wc, am[a], v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += bv;
+      if (FIX) {
+        float sv[4];
+        wino4_at_abs(wc, as[a], sv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vv[a][j] = v[j]; tau[a][j] = fx.kappa_eps * sv[j]; }
+      }
       if (relu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
       const long oo = ob + (long)a * W;
       if (EDGE) {   // outputs past the border are dropped
-        if (4 * ty + a >= H) break;
+        if (4 * ty + a >= H) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (4 * tx + j < W) {
@@ -463,6 +544,79 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
         v[2] = mk.z > 0.f ? v[2] : 0.f; v[3] = mk.w > 0.f ? v[3] : 0.f;
       }
       *reinterpret_cast<float4*>(y + oo) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (FIX) {
+      unsigned flags = 0;   // bit 4a + j
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (fabsf(vv[a][j]) < tau[a][j]) flags |= 1u << (4 * a + j);
+#pragma unroll
+      for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+        for (int wx = 0; wx < 2; ++wx) {   // the four 2x2 pool windows of the tile (tiles are 4-aligned, windows 2-aligned)
+          float top = 0.f, second = 0.f, tw = 0.f;   // post-ReLU values: a window of non-positive outputs pools to 0 anyway
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int a = 2 * wy + (e >> 1), j = 2 * wx + (e & 1);
+            const float rv = fmaxf(vv[a][j], 0.f);
+            if (rv > top) { second = top; top = rv; } else if (rv > second) second = rv;
+            tw = fmaxf(tw, tau[a][j]);
+          }
+          if (top > 0.f && top - second < tw) flags |= 0x33u << (8 * wy + 2 * wx);
+        }
+      while (flags) {
+        const int bit = __ffs((int)flags) - 1;
+        flags &= flags - 1;
+        const int a = bit >> 2, j = bit & 3;
+        if (EDGE && (4 * ty + a >= H || 4 * tx + j >= W)) continue;
+        const unsigned pos = atomicAdd(fx.count, 1u);
+        if (pos < fx.cap) fx.list[pos] = (unsigned)(ob + (long)a * W + j);
+      }
+    }
+  }
+}
+
+// One wave per listed output: y = relu?(sum_{c,dy,dx} x[n][c][yy+dy-1][xx+dx-1] w[m][c][dy][dx] + bias[m]); lane l takes the
+// channels l, l + 64, ... in ascending order (fma chain over its taps), then a fixed butterfly over the lanes.
+__global__ __launch_bounds__(256) void wino_fixup_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         const unsigned int* __restrict__ list, const unsigned int* __restrict__ count,
+                                                         unsigned cap, int C, int Mch, int H, int W, int relu) {
+  const unsigned n_fix = min(*count, cap);
+  const int lane = threadIdx.x & 63;
+  const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), waves = gridDim.x * 4;
+  const long HW = (long)H * W;
+  for (unsigned i = wave; i < n_fix; i += waves) {
+    const unsigned idx = list[i];
+    const int xx = (int)(idx % W);
+    unsigned r = idx / W;
+    const int yy = (int)(r % H); r /= H;
+    const int m = (int)(r % Mch);
+    const int n = (int)(r / Mch);
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float* xp = x + ((long)n * C + c) * HW;
+      const float* wp = w + ((long)m * C + c) * 9;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int py = yy + dy - 1;
+        if (py < 0 || py >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int px = xx + dx - 1;
+          if (px < 0 || px >= W) continue;
+          acc = fmaf(xp[(long)py * W + px], wp[dy * 3 + dx], acc);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      float v = acc + (bias ? bias[m] : 0.f);
+      if (relu) v = fmaxf(v, 0.f);
+      y[idx] = v;
     }
   }
 }
@@ -730,14 +884,16 @@ inline int nblk(long n, int cap) {
 
 }  // namespace
 
-// UMPR_WINO_F4: 0 = F(2x2,3x3) everywhere; 1 (default) = F(4x4,3x3) for the data gradient only; 2 = forward as well.
-// The backward pass is linear in its inputs (the ReLU / pool decisions were taken in forward), so the larger tile's
-// rounding stays a 5e-6 perturbation of the gradient.  In FORWARD the same rounding flips 15x more ReLU / max-pool
-// decisions than the direct kernel's 3e-7 does: predictions stay within 3e-6 of the reference, but the first layers'
-// gradients move to 5e-3 relative L2 from the float64 run where the reference's own fp32 is at 1.5e-3
-// (golden umpr_full_V1_B2_randnM) - outside the parity bound, hence opt-in (36.6 instead of 39 ms per step).
+// UMPR_WINO_F4: 0 = F(2x2,3x3) everywhere; 1 = F(4x4,3x3) for the data gradient only (the round-2 default);
+// 2 (default since round 3) = the training forward as well.  The backward pass is linear in its inputs (the ReLU / pool
+// decisions were taken in forward), so the larger tile's rounding stays a ~1e-6 perturbation of the gradient.  In FORWARD the
+// same rounding would flip several times more ReLU / max-pool decisions than the direct kernel's 1.7e-7 does (round 2, textbook
+// points: the first layers' gradients of golden umpr_full_V1_B2_randnM moved to 5e-3 relative L2 from the float64 run where the
+// reference's own fp32 is at 1.5e-3).  Round 3 removes the cause twice over: better-conditioned interpolation points (half the
+// rounding) and the decision fix-up of wino4_output_kernel / wino_fixup_kernel, which retakes every decision the tile's rounding
+// could change at the direct kernel's accuracy (the same fixture: 8e-4; tools/count_flips.py counts the decisions).
 int umpr_wino_f4_mode() {
-  static const int mode = umpr_env_int("UMPR_WINO_F4", 1);   // function-local: also read by conv3x3.hip's initialisers
+  static const int mode = umpr_env_int("UMPR_WINO_F4", 2);   // function-local: also read by conv3x3.hip's initialisers
   return mode;
 }
 // Inference (umpr_set_conv_inference, per host thread): no backward pass will read this forward's ReLU / pool decisions,
@@ -825,15 +981,28 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
   float* V = U + (size_t)planes * MT * WBM * S * WK;
   float* Mx = V + (size_t)planes * S * WK * Tpad;
   if (!weights_ready) {
-    if (f4) wino4_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
+    if (f4) wino4_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed, wino4_consts());
     else wino_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
     UMPR_LAUNCH_CHECK("wino_weights");
   }
   const long TT = (T + WBN - 1) / WBN;
+  // decision fix-up (training forward on the 4x4 tile only): counter in the 64 spare floats behind Mx, list in V once the GEMM
+  // has consumed it
+  static const int kappa = umpr_env_int("UMPR_WINO_FIX_KAPPA", 64);   // 0 disables
+  const bool fix = f4 && !transposed && !t_wino_infer && kappa > 0 && mask == nullptr;
+  WinoFix fx{nullptr, nullptr, 0u, 0.f};
+  if (fix) {
+    fx.count = reinterpret_cast<unsigned int*>(Mx + (size_t)planes * MT * WBM * Tpad);
+    fx.list = reinterpret_cast<unsigned int*>(V);
+    const size_t vfl = (size_t)planes * S * WK * Tpad;
+    fx.cap = (unsigned)(vfl < (size_t)0x7fffffff ? vfl : (size_t)0x7fffffff);
+    fx.kappa_eps = (float)kappa * 5.9604644775390625e-08f;
+    UMPR_REQUIRE((long)N * M * H * W < 0xffffffffL, "winograd fix-up: output tensor too large for 32-bit element indices");
+  }
   if (f4 && edge)
-    wino4_input_kernel<true><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
+    wino4_input_kernel<true><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN, wino4_consts(), fx.count);
   else if (f4)
-    wino4_input_kernel<false><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
+    wino4_input_kernel<false><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN, wino4_consts(), fx.count);
   else if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)S * WK * TT * WBN / 2, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
   else
@@ -848,10 +1017,18 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
     else wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_gemm");
+  if (f4 && fix) {
+    if (edge) wino4_output_kernel<true, true><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu, wino4_consts(), fx);
+    else wino4_output_kernel<false, true><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu, wino4_consts(), fx);
+    UMPR_LAUNCH_CHECK("wino_output");
+    wino_fixup_kernel<<<128, 256, 0, s>>>(x, w, bias, y, fx.list, fx.count, fx.cap, C, M, H, W, relu);
+    UMPR_LAUNCH_CHECK("wino_fixup");
+    return 0;
+  }
   if (f4 && edge)
-    wino4_output_kernel<true><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
+    wino4_output_kernel<true, false><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu, wino4_consts(), fx);
   else if (f4)
-    wino4_output_kernel<false><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
+    wino4_output_kernel<false, false><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu, wino4_consts(), fx);
   else if ((W / 2) % 2 == 0)
     wino_output_pair_kernel<<<nblk((long)M * T / 2, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu);
   else
@@ -1034,13 +1211,14 @@ __global__ void wino_bias_sum_kernel(const float* __restrict__ part, float* __re
 // tile of the output gradient, d_t the 6x6 input tile, A = (A^T)^T (6x4), G (6x3) as above: 36 GEMMs over a quarter of the
 // tiles - 4x fewer multiplies than the direct weight gradient (F(3x3,2x2): 2.25x).
 // Gy[xi][m][t] = (A g A^T)[xi];  columns t in [T, Tw) are written as zeros
-__device__ __forceinline__ void wino4_a(const float g0, const float g1, const float g2, const float g3, float* __restrict__ o) {
-  const float s02 = g0 + g2, s13 = g1 + g3, e = g0 + 4.f * g2, f = 2.f * g1 + 8.f * g3;
-  o[0] = g0; o[1] = s02 + s13; o[2] = s02 - s13; o[3] = e + f; o[4] = e - f; o[5] = g3;
+__device__ __forceinline__ void wino4_a(const Wino4C& c, const float g0, const float g1, const float g2, const float g3,
+                                        float* __restrict__ o) {
+  const float ea = g0 + c.a2 * g2, oa = c.a * g1 + c.a3 * g3, eb = g0 + c.b2 * g2, ob = c.b * g1 + c.b3 * g3;
+  o[0] = g0; o[1] = ea + oa; o[2] = ea - oa; o[3] = eb + ob; o[4] = eb - ob; o[5] = g3;
 }
 template <bool EDGE>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Gy, int N, int Mch, int H,
-                                                       int W, long Tpad, long Tw, int Mpad) {
+                                                       int W, long Tpad, long Tw, int Mpad, Wino4C wc) {
   const int TH = (H + 3) / 4, TW = (W + 3) / 4;
   const long T = (long)N * TH * TW;
   const long total = (long)Mch * Tw;
@@ -1070,16 +1248,16 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
           const float v = src[ok ? (long)a * W + j : 0];
           d[j] = ok ? v : 0.f;
         }
-        wino4_a(d[0], d[1], d[2], d[3], e[a]);
+        wino4_a(wc, d[0], d[1], d[2], d[3], e[a]);
         continue;
       }
       const float4 g = *reinterpret_cast<const float4*>(src + (long)a * W);
-      wino4_a(g.x, g.y, g.z, g.w, e[a]);
+      wino4_a(wc, g.x, g.y, g.z, g.w, e[a]);
     }
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       float o[6];
-      wino4_a(e[0][b], e[1][b], e[2][b], e[3][b], o);
+      wino4_a(wc, e[0][b], e[1][b], e[2][b], e[3][b], o);
 #pragma unroll
       for (int a = 0; a < 6; ++a) dst[(long)(a * 6 + b) * per] = o[a];
     }
@@ -1088,15 +1266,15 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
 
 // dw[m][c][3][3] (+)= G^T (sum_split P[split][.][m][c]) G for 36 planes; the splits are shared out over four thread groups
 // (q = g, g+4, ... in order) and the groups combined in order through LDS, as in wino_wgrad_finish_wide_kernel
-__device__ __forceinline__ void wino4_gt(const float* __restrict__ v, int stride, float* __restrict__ o) {
-  const float s12 = v[stride] + v[2 * stride], d12 = v[2 * stride] - v[stride];
+__device__ __forceinline__ void wino4_gt(const Wino4C& c, const float* __restrict__ v, int stride, float* __restrict__ o) {
+  const float s12 = v[stride] + v[2 * stride], d12 = v[stride] - v[2 * stride];
   const float s34 = v[3 * stride] + v[4 * stride], d34 = v[3 * stride] - v[4 * stride];
-  o[0] = 0.25f * v[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
-  o[1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
-  o[2] = (1.f / 6.f) * (s34 - s12) + v[5 * stride];
+  o[0] = c.g0 * v[0] + c.ca * s12 + c.cb * s34;
+  o[1] = (c.ca * c.a) * d12 + (c.cb * c.b) * d34;
+  o[2] = (c.ca * c.a2) * s12 + (c.cb * c.b2) * s34 + v[5 * stride];
 }
 __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __restrict__ P, int splits, int Mch, int C, int Mpad,
-                                                                 int Cpad, float* __restrict__ dw, int accumulate) {
+                                                                 int Cpad, float* __restrict__ dw, int accumulate, Wino4C wc) {
   __shared__ float red[3][36][64];
   const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int chunks = (C + 63) / 64;
@@ -1126,13 +1304,13 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       float o[3];
-      wino4_gt(v + b, 6, o);
+      wino4_gt(wc, v + b, 6, o);
       gv[0][b] = o[0]; gv[1][b] = o[1]; gv[2][b] = o[2];
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       float o[3];
-      wino4_gt(gv[a], 1, o);
+      wino4_gt(wc, gv[a], 1, o);
       outs[cl * 9 + a * 3 + 0] = o[0]; outs[cl * 9 + a * 3 + 1] = o[1]; outs[cl * 9 + a * 3 + 2] = o[2];
     }
   }
@@ -1404,18 +1582,18 @@ static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db
   // stays in rows of P that the finish kernel does not read.
   const bool edge = f4 && ((H % 4) != 0 || (W % 4) != 0);
   if (f4 && edge)
-    wino4_dy_kernel<true><<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
+    wino4_dy_kernel<true><<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad, wino4_consts());
   else if (f4)
-    wino4_dy_kernel<false><<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
+    wino4_dy_kernel<false><<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad, wino4_consts());
   else if ((W / 2) % 2 == 0)
     wino_dy_pair_kernel<<<nblk((long)Cout * g.Tpad / 2, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   else
     wino_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   UMPR_LAUNCH_CHECK("wino_dy");
   if (f4 && edge)
-    wino4_input_kernel<true><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
+    wino4_input_kernel<true><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad, wino4_consts(), nullptr);
   else if (f4)
-    wino4_input_kernel<false><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
+    wino4_input_kernel<false><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad, wino4_consts(), nullptr);
   else if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)g.Cpad * g.Tpad / 2, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
   else
@@ -1430,7 +1608,7 @@ static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db
   UMPR_LAUNCH_CHECK("wino_wgrad_gemm");
   if (f4)
     wino4_wgrad_finish_kernel<<<(unsigned)((long)Cout * ((Cin + 63) / 64)), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad, dw,
-                                                                                     accumulate);
+                                                                                     accumulate, wino4_consts());
   else if (g.splits >= 8)
     wino_wgrad_finish_wide_kernel<<<(unsigned)((long)Cout * ((Cin + 63) / 64)), 256, 0, s>>>(P, g.splits, Cout, Cin, g.Mpad, g.Cpad,
                                                                                          dw, accumulate);
