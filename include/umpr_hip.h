@@ -47,6 +47,16 @@ int umpr_set_gemm_bf16(int on);
  * decisions of this forward.  Predictions move by ~3e-6.  Set it around umpr_vgg16_features_fwd / umpr_conv3x3_fwd. */
 int umpr_set_conv_inference(int on);
 
+/* A 2x2 max-pool will consume the output of the next umpr_conv3x3_fwd calls of this host thread (umpr_vgg16_features_fwd sets
+ * it itself around conv3_3 / conv4_3 / conv5_3): the decision fix-up of the F(4x4,3x3) training forward (winograd.hip) then
+ * covers the pool windows' argmax as well as the ReLU signs.  Callers that chain umpr_conv3x3_fwd + umpr_maxpool2_fwd
+ * themselves set it likewise. */
+int umpr_set_conv_pool_follows(int on);
+
+/* Test / tooling aid: number of outputs the most recent decision fix-up pass of this host thread listed for recomputation
+ * (-1: none yet).  Synchronises the device. */
+long umpr_debug_wino_fix_count(void);
+
 /* ---- K1-K3: embedding lookup + bidirectional packed GRU + the reference's double un-sort ---------------------
  * Replaces nn.Embedding (model.py:262-264) + ImprovedRnn.forward (model.py:12-21) for one review tensor.
  * ids [N*L] int64; emb [vocab][E]; GRU weights in nn.GRU layout (gate order r,z,n): w_ih [192][E], w_hh [192][64],

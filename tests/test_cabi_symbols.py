@@ -35,7 +35,8 @@ def parse_header():
                     codes += "i"
                 else:
                     raise AssertionError(f"unparsed argument {a!r} of {name}")
-        rc = "s" if "char" in ret else ("z" if "size_t" in ret else ("p" if "void*" in ret.replace(" ", "") else "i"))
+        rc = "s" if "char" in ret else ("z" if "size_t" in ret else ("p" if "void*" in ret.replace(" ", "") else
+                                                                       ("l" if re.search(r"\blong\b", ret) else "i")))
         protos[name] = (codes, rc)
     return protos
 

@@ -54,7 +54,9 @@ def main():
         yc = F.relu(F.conv2d(x32, w, b, padding=1))
         y = torch.empty(n, cout, hw, hw, device=dev)
         wt = torch.empty(L.size("umpr_conv3x3_pack_bytes", n, cin, cout, hw, hw) // 4, device=dev)
+        L.call("umpr_set_conv_pool_follows", int(idx in (2, 7, 14, 21, 28)))      # as umpr_vgg16_features_fwd does
         L.call("umpr_conv3x3_fwd", x32.to(dev), w.to(dev), b.to(dev), y, n, cin, hw, hw, cout, 1, wt, wt.numel() * 4, st)
+        L.call("umpr_set_conv_pool_follows", 0)
         yh = y.cpu()
         fh, fc = int(((yh > 0) != (y64 > 0)).sum()), int(((yc > 0) != (y64 > 0)).sum())
         tot["hip_relu"] += fh; tot["cpu_relu"] += fc; tot["relu_n"] += y64.numel()

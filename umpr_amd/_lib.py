@@ -94,6 +94,8 @@ SIGNATURES = {
     "umpr_debug_poison_lds": ("pp", "i"),
     "umpr_set_gemm_bf16": ("i", "i"),
     "umpr_set_conv_inference": ("i", "i"),
+    "umpr_set_conv_pool_follows": ("i", "i"),
+    "umpr_debug_wino_fix_count": ("", "l"),
     "umpr_profile_enable": ("i", "i"),
     "umpr_profile_reset": ("", "i"),
     "umpr_profile_read": ("ippp", "i"),
@@ -123,7 +125,8 @@ class _Lib:
         for name, (args, ret) in SIGNATURES.items():
             f = getattr(self.cdll, name)
             f.argtypes = [_T[c] for c in args]
-            f.restype = {"i": ctypes.c_int, "z": ctypes.c_size_t, "s": ctypes.c_char_p, "p": ctypes.c_void_p}[ret]
+            f.restype = {"i": ctypes.c_int, "z": ctypes.c_size_t, "s": ctypes.c_char_p, "p": ctypes.c_void_p,
+                         "l": ctypes.c_long}[ret]
             self.fn[name] = f
 
     def last_error(self) -> str:

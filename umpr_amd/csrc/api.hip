@@ -112,6 +112,8 @@ int umpr_gemm_f32(const float* A, long lda, int transA, const float* B, long ldb
 // torch.autocast does to the same nn.GRU / nn.Linear / nn.Conv1d layers).  Hosts set it around a call and clear it after.
 int umpr_set_gemm_bf16(int on) { umpr_gemm_set_b16(on != 0); return 0; }
 int umpr_set_conv_inference(int on) { umpr_wino_set_inference(on != 0); return 0; }
+int umpr_set_conv_pool_follows(int on) { umpr_wino_set_pool_follows(on != 0); return 0; }
+long umpr_debug_wino_fix_count(void) { return umpr_wino_last_fix_count(); }
 
 // ------------------------------------------------------------------------------------------------ GRU
 size_t umpr_embed_gru_bidir_ws_bytes(int N, int L, int E) {
@@ -448,8 +450,11 @@ int umpr_vgg16_features_fwd(const float* images, const float* const* params, int
     for (int j = 0; j < kConvPerBlock[b]; ++j, ++ci) {
       float* y = acts + L.conv_off[ci];
       const int hw = L.conv_hw[ci];
-      if (int rc = umpr_conv3x3_run(x, params[2 * ci], 0, params[2 * ci + 1], nullptr, y, n, L.conv_cin[ci],
-                                    L.conv_cout[ci], hw, hw, 1, ws, ws_bytes / sizeof(float), s)) return rc;
+      umpr_wino_set_pool_follows(j == kConvPerBlock[b] - 1);   // the block's last convolution feeds the max-pool
+      const int rc = umpr_conv3x3_run(x, params[2 * ci], 0, params[2 * ci + 1], nullptr, y, n, L.conv_cin[ci],
+                                      L.conv_cout[ci], hw, hw, 1, ws, ws_bytes / sizeof(float), s);
+      umpr_wino_set_pool_follows(0);
+      if (rc) return rc;
       x = y;
     }
     const int hw = L.conv_hw[ci - 1];

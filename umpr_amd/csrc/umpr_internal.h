@@ -71,6 +71,8 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
 // winograd.hip
 size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W, int transposed);
 void umpr_wino_set_inference(int on);   // per host thread, see umpr_set_conv_inference
+void umpr_wino_set_pool_follows(int on);   // per host thread, see umpr_set_conv_pool_follows
+long umpr_wino_last_fix_count();            // see umpr_debug_wino_fix_count
 int umpr_wino_inference();
 int umpr_wino_f4_mode();   // UMPR_WINO_F4: 0 = F(2x2,3x3) only, 1 = F(4x4,3x3) in the backward pass, 2 = forward as well
 size_t umpr_wino_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W);

@@ -396,11 +396,42 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
 // V[xi][c][t] (c < Cpad),  t = (n*TH + ty)*TW + tx over 4x4 output tiles,  d = x[n][c][4ty-1 .. 4ty+4][4tx-1 .. 4tx+4]
 // One thread per (c, t): per input row one aligned float4 and the two halo scalars; 36 stores, each coalesced over t.
 // EDGE: the map is not a multiple of 4 (14x14): tiles hang over the right / bottom border (zero there), element-wise loads.
-template <bool EDGE>
+// "The same input" for the tie predicates below: equal to 2^-16 of the input tensor's largest magnitude.  Exact equality would
+// do for a photo's flat regions themselves, but not one layer later: the previous Winograd layers' outputs over a flat region are
+// equal only up to their own position-dependent rounding (~2e-6 of THEIR tensor's maximum, whatever the channel's own level), and
+// half the outputs of a constant image were listed (tools/fix_counts.py).  A pool decision between two outputs whose 3x3xC inputs
+// agree to 1.5e-5 of the maximum moves a gradient by that much at most.  The maximum comes from wino_absmax_kernel (one pass over
+// the input of the three pooled layers, ~0.1 ms per step; a maximum does not depend on the order of its atomics).
+__device__ __forceinline__ bool wino_same(float u, float v, float tol) { return fabsf(u - v) <= tol; }
+
+__global__ __launch_bounds__(256) void wino_absmax_kernel(const float* __restrict__ x, long n4, unsigned int* __restrict__ slot) {
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one atomic per workgroup: 16 384 of them on one word took longer than reading the tensor
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    if (m > 0.f) atomicMax(slot, __float_as_uint(m));   // non-negative floats order like their bit patterns
+  }
+}
+
+// PF (layers a max-pool follows, training forward): also publishes, per tile, which of its four 2x2 pool windows have contenders
+// with THE SAME inputs - bits[t], bit 2w = "some channel's 4x4 input patch of window w has a row that is not constant along x",
+// bit 2w+1 = "... a column that is not constant along y" (w = 2wy + wx; the zero padding counts as input).  If every row of the
+// patch is constant along x, horizontally adjacent outputs of the window see the same 3x3xC inputs and tie (exactly, for exactly
+// equal inputs, in exact arithmetic); likewise columns / vertical neighbours; both / diagonal.  See the pool rule of wino4_output_kernel.
+template <bool EDGE, bool PF>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C,
                                                           int Cpad, int H, int W, long Tpad, long Tw, Wino4C wc,
-                                                          unsigned int* __restrict__ zero) {
+                                                          unsigned int* __restrict__ zero, unsigned int* __restrict__ bits) {
   if (zero && blockIdx.x == 0 && threadIdx.x == 0) *zero = 0u;   // the fix-up list counter of this pass (see WinoFix)
+  const float tol = PF ? 1.52587890625e-05f * __uint_as_float(bits[-1]) : 0.f;   // bits[-1]: max |x| (wino_absmax_kernel)
   const int TH = (H + 3) / 4, TW = (W + 3) / 4;
   const long T = (long)N * TH * TW;
   const long total = (long)Cpad * Tw;
@@ -421,13 +452,15 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     const int x0 = 4 * tx;
     const bool okl = x0 > 0, okr = x0 + 4 < W;
     float e[6][6];   // e[a] = (row a of d) B  - the horizontal transform, applied as each row arrives
+    float prev[6];
+    unsigned rowL = 0, rowR = 0, colEq[5];   // PF: row a constant over columns 0..3 / 2..5; colEq[a] bit b: d[a][b] == d[a+1][b]
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       const int yy = 4 * ty - 1 + a;
       const bool oky = yy >= 0 && yy < H;
       const float* row = src + (oky ? yy * W : 0) + x0;
+      float d[6];
       if (EDGE) {
-        float d[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           const int xx = x0 - 1 + b;
@@ -435,14 +468,40 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
           const float v = row[ok ? b - 1 : 0 - x0];   // invalid: element (yy or 0, 0) of the plane, always in range
           d[b] = ok ? v : 0.f;
         }
-        wino4_bt(wc, d[0], d[1], d[2], d[3], d[4], d[5], e[a]);
-        continue;
+      } else {
+        const float l = row[okl ? -1 : 0];
+        const float4 m = *reinterpret_cast<const float4*>(row);
+        const float rr = row[okr ? 4 : 0];
+        d[0] = oky && okl ? l : 0.f; d[1] = oky ? m.x : 0.f; d[2] = oky ? m.y : 0.f; d[3] = oky ? m.z : 0.f;
+        d[4] = oky ? m.w : 0.f; d[5] = oky && okr ? rr : 0.f;
       }
-      const float l = row[okl ? -1 : 0];
-      const float4 m = *reinterpret_cast<const float4*>(row);
-      const float rr = row[okr ? 4 : 0];
-      wino4_bt(wc, oky && okl ? l : 0.f, oky ? m.x : 0.f, oky ? m.y : 0.f, oky ? m.z : 0.f, oky ? m.w : 0.f,
-               oky && okr ? rr : 0.f, e[a]);
+      wino4_bt(wc, d[0], d[1], d[2], d[3], d[4], d[5], e[a]);
+      if (PF) {
+        const bool mid = wino_same(d[2], d[3], tol);
+        if (mid && wino_same(d[0], d[1], tol) && wino_same(d[1], d[2], tol)) rowL |= 1u << a;
+        if (mid && wino_same(d[3], d[4], tol) && wino_same(d[4], d[5], tol)) rowR |= 1u << a;
+        if (a > 0) {
+          unsigned m6 = 0;
+#pragma unroll
+          for (int b = 0; b < 6; ++b) m6 |= (unsigned)wino_same(prev[b], d[b], tol) << b;
+          colEq[a - 1] = m6;
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) prev[b] = d[b];
+      }
+    }
+    if (PF) {
+      const unsigned colT = colEq[0] & colEq[1] & colEq[2];   // bit b: column b constant over rows 0..3
+      const unsigned colB = colEq[2] & colEq[3] & colEq[4];   // rows 2..5
+      unsigned viol = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int wy = w >> 1, wx = w & 1;
+        const unsigned rows = wx ? rowR : rowL, cols = wy ? colB : colT;
+        if (((rows >> (2 * wy)) & 0xFu) != 0xFu) viol |= 1u << (2 * w);        // rows 2wy .. 2wy+3 of the window's patch
+        if (((cols >> (2 * wx)) & 0xFu) != 0xFu) viol |= 2u << (2 * w);        // columns 2wx .. 2wx+3
+      }
+      if (viol & ~bits[t]) atomicOr(&bits[t], viol);   // textured tiles: set by their first channels, then only read
     }
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
@@ -460,16 +519,23 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
 // of the float64 one moves the gradients of all earlier layers by ~1e-3 relative L2 (tools/relu_flip_experiment.py) - five
 // times the noise means five times the flipped decisions, which is what kept the training forward on the 2x2 tile in round 2.
 // So the decisions are taken at the direct kernel's accuracy instead: the output transform flags every output whose decision
-// the tile's rounding could change - |y| < tau (ReLU), or a 2x2 pool window whose leader is less than tau ahead of the
-// runner-up - with tau = kappa * 2^-24 * S,  S = sum_ab |A^T_ia| |A^T_jb| |M_ab| the magnitude that fed that output (local and
+// the tile's rounding could change - |y| < tau (ReLU) and, in a layer that a 2x2 max-pool follows, the outputs of a pool window
+// whose leader is less than tau ahead of the runner-up - with tau = kappa * 2^-24 * S,  S = sum_ab |A^T_ia| |A^T_jb| |M_ab| the magnitude that fed that output (local and
 // scale-free: no pass over the tensor, no global maximum), and appends its index to a list; wino_fixup_kernel then recomputes
-// the listed outputs (a few per 100 000) as plain 9 C-term dot products, one wave each.  The list order depends on the
+// the listed outputs (a few per 100 000) as plain 9 C-term dot products, one wave each.
+// Pool rule and exact ties: where the image is constant - a missing photo (all zeros, src/dataset.py:142-143), the white
+// background of a product photo along the image border - neighbouring outputs tie EXACTLY in exact arithmetic, and the tile's
+// position-dependent rounding separates them by noise: every such window would be listed (a quarter of a million outputs per
+// constant image) although no choice among equals can move a gradient.  The input transform therefore publishes, per tile and
+// window, whether the contenders' inputs are identical (wino4_input_kernel<.., PF>), and a window whose leader and runner-up are
+// such equals is not listed.  The list order depends on the
 // atomics, the values do not: every listed element is recomputed independently in a fixed summation order.
 struct WinoFix {
   unsigned int* count;   // zeroed by the input-transform kernel of the same pass
   unsigned int* list;    // output element indices
   unsigned int cap;
   float kappa_eps;       // kappa * 2^-24
+  const unsigned int* tie_bits;   // per tile, from wino4_input_kernel<.., PF>; NULL: no max-pool follows, ReLU rule only
 };
 
 // y[n][m][4ty+i][4tx+j] = epilogue( (A^T M A)[i][j] ): 36 loads coalesced over t, one float4 store per output row
@@ -552,20 +618,29 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (fabsf(vv[a][j]) < tau[a][j]) flags |= 1u << (4 * a + j);
+      if (fx.tie_bits) {
+        const unsigned viol = fx.tie_bits[t];
 #pragma unroll
-      for (int wy = 0; wy < 2; ++wy)
+        for (int wy = 0; wy < 2; ++wy)
 #pragma unroll
-        for (int wx = 0; wx < 2; ++wx) {   // the four 2x2 pool windows of the tile (tiles are 4-aligned, windows 2-aligned)
-          float top = 0.f, second = 0.f, tw = 0.f;   // post-ReLU values: a window of non-positive outputs pools to 0 anyway
+          for (int wx = 0; wx < 2; ++wx) {   // the four 2x2 pool windows of the tile (tiles are 4-aligned, windows 2-aligned)
+            float top = 0.f, second = 0.f, tw = 0.f;   // post-ReLU values: a window of non-positive outputs pools to 0 anyway
+            int e1 = 0, e2 = 0;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int a = 2 * wy + (e >> 1), j = 2 * wx + (e & 1);
-            const float rv = fmaxf(vv[a][j], 0.f);
-            if (rv > top) { second = top; top = rv; } else if (rv > second) second = rv;
-            tw = fmaxf(tw, tau[a][j]);
+            for (int e = 0; e < 4; ++e) {
+              const int a = 2 * wy + (e >> 1), j = 2 * wx + (e & 1);
+              const float rv = fmaxf(vv[a][j], 0.f);
+              if (rv > top) { second = top; e2 = e1; top = rv; e1 = e; } else if (rv > second) { second = rv; e2 = e; }
+              tw = fmaxf(tw, tau[a][j]);
+            }
+            if (top > 0.f && top - second < tw) {
+              const unsigned v2 = (viol >> (2 * (2 * wy + wx))) & 3u;      // bit 0: rows not constant, bit 1: columns not constant
+              const int diff = e1 ^ e2;                                    // 1: horizontal neighbours, 2: vertical, 3: diagonal
+              const bool equals = diff == 1 ? !(v2 & 1u) : (diff == 2 ? !(v2 & 2u) : v2 == 0u);
+              if (!equals) flags |= 0x33u << (8 * wy + 2 * wx);
+            }
           }
-          if (top > 0.f && top - second < tw) flags |= 0x33u << (8 * wy + 2 * wx);
-        }
+      }
       while (flags) {
         const int bit = __ffs((int)flags) - 1;
         flags &= flags - 1;
@@ -906,6 +981,18 @@ int umpr_wino_inference() { return t_wino_infer && umpr_wino_f4_mode() >= 1; }
 static inline bool wino_f4_shape(int H, int W) {
   return 36L * ((H + 3) / 4) * ((W + 3) / 4) < 16L * (H / 2) * (W / 2);
 }
+// A 2x2 max-pool follows this forward convolution (set by the VGG16 forward around conv3_3 / conv4_3 / conv5_3; thread-local
+// like the inference hint): the decision fix-up then also covers the pool windows' argmax (see WinoFix).
+static thread_local int t_wino_pool_follows = 0;
+void umpr_wino_set_pool_follows(int on) { t_wino_pool_follows = on; }
+// test / tooling aid: the list counter of this host thread's most recent fix-up pass (device memory inside that call's workspace)
+static thread_local const unsigned int* t_last_fix_count = nullptr;
+long umpr_wino_last_fix_count() {
+  if (!t_last_fix_count) return -1;
+  unsigned int v = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, t_last_fix_count, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return (long)v;
+}
 static inline bool wino_f4_map(int H, int W, int transposed) {
   const int need = transposed || t_wino_infer ? 1 : 2;
   return umpr_wino_f4_mode() >= need && wino_f4_shape(H, W);
@@ -918,13 +1005,14 @@ size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W, int transposed) {
   auto layout = [&](bool f4) {
     const long T = f4 ? (long)N * ((H + 3) / 4) * ((W + 3) / 4) : (long)N * (H / 2) * (W / 2);
     const long Tpad = wino_tpad(T);
-    return (size_t)(f4 ? 36 : 16) * (MT * WBM * S * WK + S * WK * Tpad + MT * WBM * Tpad) + 64;
+    return (size_t)(f4 ? 36 : 16) * (MT * WBM * S * WK + S * WK * Tpad + MT * WBM * Tpad) + 64 + (f4 ? Tpad : 0);   // + fix-up counter and per-tile tie bits
   };
   const bool map4 = wino_f4_shape(H, W);
   const int mode = umpr_wino_f4_mode();
   if (!map4 || mode == 0) return layout(false);
-  if (transposed || mode >= 2) return layout(true);
-  const size_t a = layout(false), b = layout(true);   // forward, mode 1: the 2x2 tile, or the 4x4 one in inference
+  if (transposed) return layout(true);
+  // forward: the 2x2 tile (mode 1 training; in mode 2 the layers a max-pool follows) or the 4x4 one (mode 2; inference)
+  const size_t a = layout(false), b = layout(true);
   return a > b ? a : b;
 }
 
@@ -988,9 +1076,14 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
   const long TT = (T + WBN - 1) / WBN;
   // decision fix-up (training forward on the 4x4 tile only): counter in the 64 spare floats behind Mx, list in V once the GEMM
   // has consumed it
-  static const int kappa = umpr_env_int("UMPR_WINO_FIX_KAPPA", 64);   // 0 disables
+  // tau = kappa * 2^-24 * S.  The tile's error is ~9e-7 rms of rms(y) and S ~ 20 |y|, so kappa = 8 is ~8 standard deviations for a
+  // typical output (CPU emulation, tools/wino_flip_sim.py: kappa 8, 32 and 128 fix the same decisions); the list grows in
+  // proportion - 6e-6 of the outputs on the golden fixtures' images, 3e-3 on the benchmark's i.i.d.-noise images, whose deep
+  // feature maps are nearly flat (neighbouring outputs differ by ~3e-3 of their magnitude), at kappa = 8.
+  static const int kappa = umpr_env_int("UMPR_WINO_FIX_KAPPA", 8);   // 0 disables
   const bool fix = f4 && !transposed && !t_wino_infer && kappa > 0 && mask == nullptr;
-  WinoFix fx{nullptr, nullptr, 0u, 0.f};
+  WinoFix fx{nullptr, nullptr, 0u, 0.f, nullptr};
+  unsigned int* tie_bits = nullptr;
   if (fix) {
     fx.count = reinterpret_cast<unsigned int*>(Mx + (size_t)planes * MT * WBM * Tpad);
     fx.list = reinterpret_cast<unsigned int*>(V);
@@ -998,11 +1091,22 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
     fx.cap = (unsigned)(vfl < (size_t)0x7fffffff ? vfl : (size_t)0x7fffffff);
     fx.kappa_eps = (float)kappa * 5.9604644775390625e-08f;
     UMPR_REQUIRE((long)N * M * H * W < 0xffffffffL, "winograd fix-up: output tensor too large for 32-bit element indices");
+    if (t_wino_pool_follows) {   // one word per tile behind the counter (umpr_wino_ws_floats reserves Tpad + 64 floats there)
+      tie_bits = fx.count + 16;   // tie_bits[-1]: the input's largest magnitude
+      if (hipMemsetAsync(tie_bits - 1, 0, (size_t)(T + 1) * sizeof(unsigned int), s) != hipSuccess) { umpr_set_error("winograd fix-up: memset"); return -2; }
+      UMPR_REQUIRE(((long)N * C * H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "winograd fix-up: unaligned input");
+      wino_absmax_kernel<<<nblk((long)N * C * H * W / 4, 1024), 256, 0, s>>>(x, (long)N * C * H * W / 4, tie_bits - 1);
+      UMPR_LAUNCH_CHECK("wino_absmax");
+      fx.tie_bits = tie_bits;
+    }
   }
-  if (f4 && edge)
-    wino4_input_kernel<true><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN, wino4_consts(), fx.count);
-  else if (f4)
-    wino4_input_kernel<false><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN, wino4_consts(), fx.count);
+  if (f4 && edge) {
+    if (tie_bits) wino4_input_kernel<true, true><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN, wino4_consts(), fx.count, tie_bits);
+    else wino4_input_kernel<true, false><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN, wino4_consts(), fx.count, nullptr);
+  } else if (f4) {
+    if (tie_bits) wino4_input_kernel<false, true><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN, wino4_consts(), fx.count, tie_bits);
+    else wino4_input_kernel<false, false><<<nblk((long)S * WK * TT * WBN, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN, wino4_consts(), fx.count, nullptr);
+  }
   else if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)S * WK * TT * WBN / 2, 16384), 256, 0, s>>>(x, V, N, C, S * WK, H, W, Tpad, TT * WBN);
   else
@@ -1021,8 +1125,11 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
     if (edge) wino4_output_kernel<true, true><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu, wino4_consts(), fx);
     else wino4_output_kernel<false, true><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu, wino4_consts(), fx);
     UMPR_LAUNCH_CHECK("wino_output");
-    wino_fixup_kernel<<<128, 256, 0, s>>>(x, w, bias, y, fx.list, fx.count, fx.cap, C, M, H, W, relu);
+    // 2048 waves: the list is usually a few hundred outputs (most workgroups leave at once; 8192 waves cost 27 us per launch
+    // just to start and leave), each a latency-bound gather of 9 C inputs
+    wino_fixup_kernel<<<512, 256, 0, s>>>(x, w, bias, y, fx.list, fx.count, fx.cap, C, M, H, W, relu);
     UMPR_LAUNCH_CHECK("wino_fixup");
+    t_last_fix_count = fx.count;
     return 0;
   }
   if (f4 && edge)
@@ -1591,9 +1698,9 @@ static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db
     wino_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   UMPR_LAUNCH_CHECK("wino_dy");
   if (f4 && edge)
-    wino4_input_kernel<true><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad, wino4_consts(), nullptr);
+    wino4_input_kernel<true, false><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad, wino4_consts(), nullptr, nullptr);
   else if (f4)
-    wino4_input_kernel<false><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad, wino4_consts(), nullptr);
+    wino4_input_kernel<false, false><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad, wino4_consts(), nullptr, nullptr);
   else if ((W / 2) % 2 == 0)
     wino_input_pair_kernel<<<nblk((long)g.Cpad * g.Tpad / 2, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad);
   else
