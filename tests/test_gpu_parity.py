@@ -135,7 +135,7 @@ def test_conv3x3(L, dev, N, Cin, Cout, HW):
     # tools/conv_error.py on the GPU, tools/wino43_error.py on the CPU).  The stated bound there is 5e-6 of max|y| on top of the
     # 2e-5 absolute every other layer keeps.
     mode = int(os.environ.get("UMPR_WINO_F4", "2"))   # 0: F(2x2,3x3) only, 1: F(4x4,3x3) in backward, 2 (default): forward as well
-    f4_fwd = HW in (56, 28, 14) and Cin >= 32 and mode >= 2
+    f4_fwd = mode >= 2 and ((HW in (56, 28, 14) and Cin >= 32) or (HW == 112 and Cin >= 128 and Cout >= 128))
     f4_bwd = mode >= 1 and ((HW in (56, 28, 14) and Cout >= 32) or (HW == 112 and Cin >= 128 and Cout >= 128))
     check(f"conv fwd {N},{Cin},{Cout},{HW}", y, y_ref, atol=2e-5, rtol=1e-5, rel_to_max=5e-6 if f4_fwd else None)
     gz = gz_ref.to(dev)

@@ -16,6 +16,8 @@
 // The 224x224 layers, conv2_1 and the forward pass of conv2_2 stay on the direct kernels of conv3x3.hip: with 64 channels
 // on one side the batched GEMM is HBM-bound on V / M, and in forward the 4x transform traffic of the 2x2 tile costs more
 // than the MFMA time it saves.
+#include <type_traits>
+
 #include "umpr_common.h"
 #include "umpr_internal.h"
 
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     const int ty = (int)(r % TH), n = (int)(r / TH);
     const float* src = Mx + (long)m * Tpad + t;
     float am[4][6];   // A^T M, accumulated plane row by plane row
-    float as[FIX ? 4 : 1][6];   // |A^T| |M|
+    float as[4][6];   // |A^T| |M| (FIX only)
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       float q[6];
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     }
     const float bv = bias ? bias[m] : 0.f;
     const long ob = (((long)n * Mch + m) * H + 4 * ty) * W + 4 * tx;
-    float vv[FIX ? 4 : 1][4], tau[FIX ? 4 : 1][4];
+    float vv[4][4], tau[4][4];   // FIX only
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       float v[4];
@@ -837,13 +839,20 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmParams p) {
 // stage is 32 rows of 128 contiguous floats, so one wave-instruction (64 lanes x 16 B) fills two unpadded 512-B rows.
 // Unpadded rows are conflict-free for the fragment reads (32 consecutive floats per half-wave).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <int SK, int OCC>
+// FOLD: how the MFMA accumulation chains are folded into the running total.  In a Winograd GEMM the accumulation rounding is
+// the dominant error of the whole convolution (CPU ablation, round 3: with exact accumulation the 4x4 tile's result is 2-3e-7
+// rms from float64, like the direct kernel; with one fp32 chain over all channels 1e-6): the outputs are differences of plane
+// values ~20x their own size, so every eps of a partial sum counts 20-fold.  0: chains of 128 channels, fp32 total (rounds 1-2:
+// 9.2e-7 measured on the 4x4 tile); 1: chains of one 32-channel stage, fp32 total; 2: chains of one stage, FLOAT64 total (the
+// fold's cvt + v_add_f64 run under the other wave's MFMAs).
+template <int SK, int OCC, int FOLD>
 __global__ __launch_bounds__(256, OCC) void wino_gemm_dma_kernel(WinoGemmParams p) {
   constexpr int LD = 128;
   constexpr int TM = 2, TN = 2;
   constexpr int KS = SK / 2;            // MFMA k-steps per stage
   constexpr int NP = SK / 8;            // 1-KiB DMA pieces per wave, operand and stage
-  constexpr int SFLUSH = 128 / SK;      // stages per MFMA accumulation chain (128 k)
+  constexpr int SFLUSH = FOLD == 0 ? 128 / SK : 1;      // stages per MFMA accumulation chain
+  typedef typename std::conditional<FOLD == 2, double, float>::type tot_t;
   __shared__ __attribute__((aligned(1024))) float As[2][SK * LD];
   __shared__ __attribute__((aligned(1024))) float Bs[2][SK * LD];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -880,13 +889,14 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_dma_kernel(WinoGemmParams 
   };
   auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-  f32x16 acc[TM][TN], tot[TM][TN];
+  f32x16 acc[TM][TN];
+  tot_t tot[TM][TN][16];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = (tot_t)0; }
 
   const int ns = p.S * (WK / SK);
 #pragma unroll
@@ -937,7 +947,9 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_dma_kernel(WinoGemmParams 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] += (tot_t)acc[i][j][r];
   }
   float* Mb = p.Mx + ((long)xi * p.Mpad + mt * WBM) * p.Tpad + t0;
 #pragma unroll
@@ -946,7 +958,7 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_dma_kernel(WinoGemmParams 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Mb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Tpad + wn * 64 + j * 32 + l31] = tot[i][j][r];
+        Mb[(long)(wm * 64 + i * 32 + mfma_row(r, lane)) * p.Tpad + wn * 64 + j * 32 + l31] = (float)tot[i][j][r];
 }
 
 const int g_wino_dma = umpr_env_int("UMPR_WINO_DMA", 1);   // 0 off, 1: 32-deep stages, 2: 16-deep stages at 3 waves/SIMD
@@ -1116,8 +1128,11 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
   const long groups = (planes * TT + 7) / 8 * 8;
   {
     UmprProfScope prof(UMPR_K_WINO_GEMM, 2.0 * planes * (double)M * C * T, s);
-    if (g_wino_dma == 2) wino_gemm_dma_kernel<16, 3><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
-    else if (g_wino_dma) wino_gemm_dma_kernel<32, 2><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+    static const int fold = umpr_env_int("UMPR_WINO_FOLD", 1);   // measured (4x4 tile, rms of rms y): 0: 9.2e-7, 1: 6.0e-7 at the same speed, 2: 5.4e-7 for -9 % GEMM rate
+    if (g_wino_dma == 2) wino_gemm_dma_kernel<16, 3, 0><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+    else if (g_wino_dma && fold == 2) wino_gemm_dma_kernel<32, 2, 2><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+    else if (g_wino_dma && fold == 1) wino_gemm_dma_kernel<32, 2, 1><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
+    else if (g_wino_dma) wino_gemm_dma_kernel<32, 2, 0><<<(unsigned)(groups * MT), 256, 0, s>>>(p);
     else wino_gemm_kernel<<<(unsigned)(groups * MT), 256, 0, s>>>(p);
   }
   UMPR_LAUNCH_CHECK("wino_gemm");
