@@ -76,3 +76,20 @@ def test_every_environment_switch_is_in_the_built_library():
     assert len(names) >= 15, names
     missing = sorted(n for n in names if n.encode() + b"\x00" not in blob)
     assert not missing, missing
+
+
+def test_build_checks_scratch_and_dropped_compiler_requests():
+    """`make check-scratch` (no kernel spills to the private segment) and `make check-passes` (hipcc dropped no occupancy target
+    and no unroll request: -Wpass-failed) on the nine HIP sources.  Both recompile every file for gfx950 (~1 min each, run side by
+    side); hipcc cross-compiles without a GPU."""
+    import shutil
+    import subprocess
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "umpr_amd", "csrc")
+    procs = [(t, subprocess.Popen(["make", "-C", csrc, t], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+             for t in ("check-scratch", "check-passes")]
+    for target, p in procs:
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, (target, out[-3000:])
+    assert True

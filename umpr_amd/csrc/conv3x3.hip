@@ -203,7 +203,9 @@ constexpr int v2_patch_rows(int W, int BN) {
 }
 
 template <int BM, int BN, int W>
-__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv3x3_igemm_v2_kernel(ConvParams p) {
+// three workgroups per CU for the 64-pixel tail tiles, except at 224x224 where the halo patch alone is 66 KB of LDS (two fit) and
+// the staged rows take 176 registers - declaring 3 there only made hipcc report a missed occupancy target
+__global__ __launch_bounds__(256, (BN == 64 && !(BM == 128 && W == 224) ? 3 : 2)) void conv3x3_igemm_v2_kernel(ConvParams p) {
   constexpr int PR = v2_patch_rows(W, BN);
   constexpr int CC = V2_CC, KC = V2_KC;
   constexpr int RW = W + 2, PLANE = PR * RW;
