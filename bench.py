@@ -376,7 +376,7 @@ def run_workload(w, env):
     u, i_, ui, ul, il, uil, photos, labels = host_batch
     # lengths stay on the host, like the reference (src/model.py:18)
     batch = (u.to(dev), i_.to(dev), ui.to(dev), ul, il, uil, photos.to(dev), labels.to(dev))
-    loss_sum = torch.zeros((), device=dev)
+    losses = []          # device scalars, summed once after the timed region (no per-step torch kernel inside it)
 
     def barrier():
         if parallel.active():
@@ -400,7 +400,7 @@ def run_workload(w, env):
     t0 = time.perf_counter()
     for _ in range(w.steps):
         _, loss = step()
-        loss_sum += loss.detach()
+        losses.append(loss.detach())
     t_issue = time.perf_counter() - t0        # host time to ENQUEUE the steps (no wait): close to dt => host-bound
     barrier()
     dt_local = dt = time.perf_counter() - t0
@@ -462,7 +462,7 @@ def run_workload(w, env):
         "kernels": {k: {"ms_per_step": v[0] / w.steps, ("gbytes_per_s" if k == "gru" else "tflops"):
                         ((v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0) if k == "gru" else per_s(v)),
                         "launches_per_step": v[2] / w.steps} for k, v in fam.items() if v[2]},
-        "loss_mean": float(loss_sum.item()) / w.steps,
+        "loss_mean": float(torch.stack(losses).sum().item()) / w.steps,
         "host_issue_ms_per_step": 1e3 * t_issue / w.steps,
         "rccl_ranks": rccl_ranks, "ms_per_step_per_rank": per_rank_ms,
     }

@@ -156,6 +156,40 @@ int umpr_control_gate_bwd(const float* self_atte, const float* w, const float* v
                           const float* d_prefer_neg, int B, int S, int V, float* d_self_atte, float* d_view_p,
                           float* d_c_out, float* dw, float* db, float* ws, size_t ws_bytes, void* stream);
 
+/* ---- the text path in two calls per direction (round 3; csrc/text_path.hip) -----------------------------------------------
+ * The whole ReviewNet (src/model.py:157-169: R-Net GRU over the user + item pair, co-attention, S-Net u / i, merge) and the whole
+ * ControlNet (src/model.py:179-198: C-Net GRU over ui and over the pair, three C-Net heads, control S-Net, SS-Net gate), each
+ * issued back to back from C++ into ONE caller-owned arena (everything the backward reads; *_arena_bytes) and one scratch buffer
+ * (*_ws_bytes).  Same kernels and the same arithmetic as the per-stage entry points above, which these call in order; what goes
+ * away is ~20 host round trips per direction (a UMPR-R training step is 0.9 ms of kernels).
+ * ids_pair [2N][L]: user rows then item rows (umpr_concat_ids); lengths / order [2N] with the item half's order offset by N.
+ * b16_gemm: GEMM-shaped products on the bf16 pipe (as umpr_set_gemm_bf16); b16_scores: the co-attention score contraction in
+ * bf16 (as umpr_coattention_fwd_bf16); need_grad = 0 skips the GRU gate records (inference). */
+int umpr_concat_ids(const int64_t* ids_u, const int64_t* ids_i, long n_each, int64_t* dst, void* stream);
+size_t umpr_review_net_arena_bytes(int B, int S, int L);
+size_t umpr_review_net_ws_bytes(int B, int S, int L, int E);
+/* params (15): w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, M, Ms_u, Ws_u, Ms_i, Ws_i, W_u, W_i; out [B][128] */
+int umpr_review_net_fwd(const int64_t* ids_pair, const float* emb, int E, const float* const* params, const int32_t* lengths,
+                        const int32_t* order, int B, int S, int L, int b16_gemm, int b16_scores, int need_grad, void* arena,
+                        float* out, float* ws, size_t ws_bytes, void* stream);
+/* grads: 15 pointers in the order of params, each overwritten */
+int umpr_review_net_bwd(const int64_t* ids_pair, const float* emb, int E, const float* const* params, const int32_t* lengths,
+                        const int32_t* order, int B, int S, int L, int b16_gemm, const void* arena, const float* d_out,
+                        float* const* grads, float* ws, size_t ws_bytes, void* stream);
+size_t umpr_control_net_arena_bytes(int B, int S_ui, int L_ui, int S, int L, int KC, int V);
+size_t umpr_control_net_ws_bytes(int B, int S_ui, int L_ui, int S, int L, int E, int KC, int KS, int V);
+/* params (16): the C-Net GRU's eight, Wc [KC][128][KS], bc, Wl [V][KC], bl, Ms, Ws, ssW [128], ssb [1];
+ * outputs c_u, c_i, prefer_pos, prefer_neg [B][V] */
+int umpr_control_net_fwd(const int64_t* ids_ui, const int64_t* ids_pair, const float* emb, int E, const float* const* params,
+                         const int32_t* len_ui, const int32_t* ord_ui, const int32_t* len_pair, const int32_t* ord_pair, int B,
+                         int S_ui, int L_ui, int S, int L, int KC, int KS, int V, float thr, int b16_gemm, int need_grad, void* arena,
+                         float* c_u, float* c_i, float* prefer_pos, float* prefer_neg, float* ws, size_t ws_bytes, void* stream);
+int umpr_control_net_bwd(const int64_t* ids_ui, const int64_t* ids_pair, const float* emb, int E, const float* const* params,
+                         const int32_t* len_ui, const int32_t* ord_ui, const int32_t* len_pair, const int32_t* ord_pair, int B,
+                         int S_ui, int L_ui, int S, int L, int KC, int KS, int V, int b16_gemm, const void* arena, const float* d_cu,
+                         const float* d_ci, const float* d_pp, const float* d_pn, float* const* grads, float* ws, size_t ws_bytes,
+                         void* stream);
+
 /* ---- K10: VGG16-D feature extractor (torchvision.models.vgg16, call site model.py:204-207,217) ---------------
  * images [n][3][224][224]; params: 32 pointers = 13 x (conv weight [Cout][Cin][3][3], bias) then 3 x (fc weight
  * [out][in], bias) in torchvision order.  acts: activation arena (umpr_vgg16_act_bytes), kept for backward.

@@ -85,6 +85,15 @@ SIGNATURES = {
     "umpr_vgg16_classifier_bwd_compact": ("piippppppzp", "i"),
     "umpr_vgg16_classifier_fwd_compact_bf16": ("piiiuppppzp", "i"),
     "umpr_vgg16_classifier_bwd_compact_bf16": ("piippppppzp", "i"),
+    "umpr_concat_ids": ("pplpp", "i"),
+    "umpr_review_net_arena_bytes": ("iii", "z"),
+    "umpr_review_net_ws_bytes": ("iiii", "z"),
+    "umpr_review_net_fwd": ("ppipppiiiiiipppzp", "i"),
+    "umpr_review_net_bwd": ("ppipppiiiippppzp", "i"),
+    "umpr_control_net_arena_bytes": ("iiiiiii", "z"),
+    "umpr_control_net_ws_bytes": ("iiiiiiiii", "z"),
+    "umpr_control_net_fwd": ("pppipppppiiiiiiiifiippppppzp", "i"),
+    "umpr_control_net_bwd": ("pppipppppiiiiiiiiipppppppzp", "i"),
     "umpr_head_fwd": ("pppppppppppppfiiipppppppp", "i"),
     "umpr_head_bwd": ("pppppppppppfiiippppppppppppppppppppp", "i"),
     "umpr_bce_head_fwd": ("plpppiipppzp", "i"),

@@ -10,6 +10,7 @@ Reference lines: UMPR.__init__ src/model.py:233-255, UMPR.forward src/model.py:2
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import threading
@@ -312,6 +313,89 @@ class _Control(torch.autograd.Function):
         return (dX_ui, dX_u, dX_i, None, None, *ret)
 
 
+# --------------------------------------------------------------------------------------------- fused text path
+# UMPR.forward issues the text path through these two Functions: ONE C call per direction each (csrc/text_path.hip), one arena
+# tensor saved for backward.  The stage-level Functions above remain the unit the parity tests pin kernel by kernel.
+class _ReviewNetF(torch.autograd.Function):
+    """The whole ReviewNet (src/model.py:157-169) on the user+item pair: params = the R-Net GRU's eight, M, Ms_u, Ws_u, Ms_i,
+    Ws_i, W_u, W_i."""
+
+    @staticmethod
+    def forward(ctx, ids_pair, lens, order, emb, dims, b16_gemm, b16_scores, *params):
+        B, S, L = dims
+        E = emb.shape[1]
+        dev = ids_pair.device
+        need = any(ctx.needs_input_grad)
+        arena = torch.empty(lib().size("umpr_review_net_arena_bytes", B, S, L) // 4, device=dev, dtype=torch.float32)
+        out = torch.empty(B, D, device=dev, dtype=torch.float32)
+        ws, wsb = _ws(lib().size("umpr_review_net_ws_bytes", B, S, L, E), dev)
+        cp = [_c(p) for p in params]
+        keep, parr = _ptr_array(cp)
+        lib().call("umpr_review_net_fwd", ids_pair, emb, E, parr, lens, order, B, S, L, int(b16_gemm), int(b16_scores), int(need),
+                   arena, out, ws, wsb, stream_ptr())
+        ctx.param_objs = params
+        ctx.meta = (B, S, L, int(b16_gemm))
+        if need:
+            ctx.save_for_backward(ids_pair, lens, order, emb, arena, *cp)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        ids_pair, lens, order, emb, arena, *cp = ctx.saved_tensors
+        B, S, L, b16 = ctx.meta
+        E = emb.shape[1]
+        tg, direct = _grad_targets(ctx.param_objs)     # every parameter of the ReviewNet is used by this node only
+        ws, wsb = _ws(lib().size("umpr_review_net_ws_bytes", B, S, L, E), ids_pair.device)
+        keep_p, parr = _ptr_array(cp)
+        keep_g, garr = _ptr_array(tg)
+        lib().call("umpr_review_net_bwd", ids_pair, emb, E, parr, lens, order, B, S, L, b16, arena, _c(d_out), garr, ws, wsb,
+                   stream_ptr())
+        return (None, None, None, None, None, None, None, *_grad_returns(ctx.param_objs, tg, direct))
+
+
+class _ControlNetF(torch.autograd.Function):
+    """The whole ControlNet (src/model.py:179-198): params = the C-Net GRU's eight, cnn weight / bias, linear weight / bias,
+    control S-Net Ms / Ws, SS-Net weight / bias.  Returns (c_u, c_i, prefer_pos, prefer_neg)."""
+
+    @staticmethod
+    def forward(ctx, ids_ui, ids_pair, lens_ui, ord_ui, lens, order, emb, dims, thr, b16_gemm, *params):
+        B, S_ui, L_ui, S, L = dims
+        E = emb.shape[1]
+        KC, _, KS = params[8].shape
+        V = params[10].shape[0]
+        dev = ids_pair.device
+        need = any(ctx.needs_input_grad)
+        arena = torch.empty(lib().size("umpr_control_net_arena_bytes", B, S_ui, L_ui, S, L, KC, V) // 4, device=dev,
+                            dtype=torch.float32)
+        outs = torch.empty(4, B, V, device=dev, dtype=torch.float32)
+        ws, wsb = _ws(lib().size("umpr_control_net_ws_bytes", B, S_ui, L_ui, S, L, E, KC, KS, V), dev)
+        cp = [_c(p) for p in params]
+        keep, parr = _ptr_array(cp)
+        lib().call("umpr_control_net_fwd", ids_ui, ids_pair, emb, E, parr, lens_ui, ord_ui, lens, order, B, S_ui, L_ui, S, L, KC, KS, V,
+                   float(thr), int(b16_gemm), int(need), arena, outs[0], outs[1], outs[2], outs[3], ws, wsb, stream_ptr())
+        ctx.param_objs = params
+        ctx.meta = (B, S_ui, L_ui, S, L, KC, KS, V, int(b16_gemm))
+        ctx.set_materialize_grads(False)
+        if need:
+            ctx.save_for_backward(ids_ui, ids_pair, lens_ui, ord_ui, lens, order, emb, arena, *cp)
+        return outs[0], outs[1], outs[2], outs[3]
+
+    @staticmethod
+    def backward(ctx, d_cu, d_ci, d_pp, d_pn):
+        ids_ui, ids_pair, lens_ui, ord_ui, lens, order, emb, arena, *cp = ctx.saved_tensors
+        B, S_ui, L_ui, S, L, KC, KS, V, b16 = ctx.meta
+        E = emb.shape[1]
+        dev = ids_pair.device
+        d = [(_c(t) if t is not None else torch.zeros(B, V, device=dev)) for t in (d_cu, d_ci, d_pp, d_pn)]
+        tg, direct = _grad_targets(ctx.param_objs)
+        ws, wsb = _ws(lib().size("umpr_control_net_ws_bytes", B, S_ui, L_ui, S, L, E, KC, KS, V), dev)
+        keep_p, parr = _ptr_array(cp)
+        keep_g, garr = _ptr_array(tg)
+        lib().call("umpr_control_net_bwd", ids_ui, ids_pair, emb, E, parr, lens_ui, ord_ui, lens, order, B, S_ui, L_ui, S, L, KC, KS,
+                   V, b16, arena, d[0], d[1], d[2], d[3], garr, ws, wsb, stream_ptr())
+        return (None,) * 10 + tuple(_grad_returns(ctx.param_objs, tg, direct))
+
+
 # --------------------------------------------------------------------------------------------- K10
 # Data parallel: callables(block) run on the host each time the feature backward has enqueued one VGG block (4 .. 0) - the
 # gradient reducer starts that block's all-reduce from there (parallel.GradReducer).  Only when the gradients are written
@@ -511,6 +595,7 @@ class _Head(torch.autograd.Function):
         lib().call("umpr_head_fwd", rr, *args, fw, fb, labels, float(rate), B, V, Pc, pred, loss, z, img_emb, pm, nm,
                    pne, stream_ptr())
         ctx.meta = (float(rate), B, V, Pc)
+        ctx.param_objs = (pos_v, neg_v, lw, lb, fw, fb)
         ctx.opt = [t is not None for t in args]
         keep = [t if t is not None else torch.empty(0, **f) for t in args]
         ctx.save_for_backward(rr, *keep, fw, labels, pred, z, img_emb, pm, nm, pne)
@@ -529,19 +614,27 @@ class _Head(torch.autograd.Function):
         d_loss = d_loss.reshape(1).contiguous()
         d_pred = _c(d_pred) if d_pred is not None else None
         d_rr = torch.empty_like(rr)
-        d_fw, d_fb = torch.empty_like(fw), torch.empty(1, **f)
+        # the head's own parameters (visual head, linear_fusion): written straight into the optimiser's arena when it marked them
+        # fresh (no temporaries, no AccumulateGrad add kernels - six tiny torch launches per step in round 2)
+        po = ctx.param_objs
         if V > 0:
+            tg, direct = _grad_targets(po)                       # (pos_v, neg_v, lw, lb, fw, fb)
+            d_pos, d_neg, d_lw, d_lb, d_fw, d_fb = tg
             d_cu, d_ci, d_pp, d_pn = (torch.empty(B, V, **f) for _ in range(4))
             d_vgg = torch.empty_like(vgg)
-            d_pos, d_neg = torch.empty_like(pos_v), torch.empty_like(neg_v)
-            d_lw, d_lb = torch.empty_like(lw), torch.empty(1, **f)
         else:
+            tg, direct = _grad_targets(po[4:])
+            d_fw, d_fb = tg
             d_cu = d_ci = d_pp = d_pn = d_vgg = d_pos = d_neg = d_lw = d_lb = None
         opt = lambda t: t if (t is not None and t.numel() > 0) else None
         lib().call("umpr_head_bwd", rr, opt(c_u), opt(c_i), opt(pp), opt(pn), opt(vgg), opt(pos_v), opt(neg_v), opt(lw),
                    fw, labels, rate, B, V, Pc, pred, z, img_emb, pm, nm, pne, d_loss, d_pred, d_rr, d_cu, d_ci, d_pp,
                    d_pn, d_vgg, d_pos, d_neg, d_lw, d_lb, d_fw, d_fb, stream_ptr())
-        return d_rr, d_cu, d_ci, d_pp, d_pn, d_vgg, d_pos, d_neg, d_lw, d_lb, d_fw, d_fb, None, None, None, None
+        if V > 0:
+            r = _grad_returns(po, tg, direct)
+        else:
+            r = [None] * 4 + _grad_returns(po[4:], tg, direct)
+        return d_rr, d_cu, d_ci, d_pp, d_pn, d_vgg, r[0], r[1], r[2], r[3], r[4], r[5], None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- module tree
@@ -713,11 +806,15 @@ class UMPR(nn.Module):
         self.last_loss_terms = None
         # Parameters whose backward node can write the gradient straight into the optimiser's arena (_grad_targets):
         # everything in the review / control nets (GRU weights accumulate in place across their uses) and, set by VGG16
-        # itself, the VGG stack.  The head's parameters keep autograd's accumulation.
-        for mod in (self.review_net, getattr(self, "control_net", None)):
+        # itself, the VGG stack; the head's own parameters (visual head, linear_fusion) by the head node.
+        for mod in (self.review_net, getattr(self, "control_net", None), self.linear_fusion):
             if mod is not None:
                 for p in mod.parameters():
                     p._umpr_direct = True
+        if not config.review_net_only:
+            vn = self.visual_net
+            for p in (vn.pos_v_emb, vn.neg_v_emb, vn.linear.weight, vn.linear.bias):
+                p._umpr_direct = True      # written by the head's backward node (_Head), once per step
 
     @staticmethod
     def _host_perm(lengths, device):
@@ -744,32 +841,64 @@ class UMPR(nn.Module):
         the same module on both): the recurrent kernels are bound by the latency of their <= 20 dependent time steps, not by
         work, so one launch over 2N sequences costs what a launch over N does, and the input-projection GEMM doubles its M.
         Each half keeps its own permutation (the reference's double un-sort is per call): item rows and their destination
-        rows are offset by N."""
+        rows are offset by N.  (Stage-level form with device-side concatenations: kept for callers that hold device index
+        tensors; UMPR.forward builds the pair on the host, _index_upload.)"""
         B, S, L = user_reviews.shape
         N = B * S
         ids = torch.cat([user_reviews.view(N, L), item_reviews.view(N, L)])
         return ids, torch.cat([lu, li]), torch.cat([ou, oi + N]), N
 
-    def _review(self, pair, S, L, emb):
-        ids, lens, order, N = pair
-        B = N // S
-        rn = self.review_net
-        g_u, g_i = rn.r_net.gru(ids, lens, order, emb, split=N)
-        gru_u, gru_i = g_u.view(B, S * L, D), g_i.view(B, S * L, D)
-        return _ReviewHead.apply(gru_u, gru_i, S, L, rn.r_net.M, rn.s_net_u.Ms, rn.s_net_u.Ws, rn.s_net_i.Ms,
-                                 rn.s_net_i.Ws, rn.linear_u.weight, rn.linear_i.weight, self.compute_dtype == "bf16")
+    _INDEX_RING = {}     # device -> [pinned host buffers, events, position]: staging for the per-step index upload
 
-    def _control(self, pair, S, L, ui_reviews, lui, oui, emb):
-        ids, lens, order, N = pair
-        B = N // S
-        _, S_ui, L_ui = ui_reviews.shape
+    @classmethod
+    def _index_upload(cls, u_lengths, i_lengths, ui_lengths, device):
+        """lengths stay on the host (src/model.py:18 ``lengths.cpu()``): the descending, NON-stable torch.sort that
+        pack_padded_sequence runs defines each review tensor's sentence permutation (SURVEY.md header fact 1).  Everything the
+        kernels need of it - lengths and sorted indices of the user+item pair (item half offset by N) and of the ui reviews -
+        travels to the device as ONE int32 tensor per step, from a small ring of pinned buffers (a slot is reused 8 steps later;
+        its event is only waited for if the GPU is that far behind)."""
+        parts = []
+        flats = []
+        for ln in (u_lengths, i_lengths):
+            flat = ln.reshape(-1).cpu()
+            _, si = torch.sort(flat, descending=True)
+            flats.append((flat, si))
+        N = flats[0][0].numel()
+        parts += [flats[0][0], flats[1][0], flats[0][1], flats[1][1] + N]
+        n_ui = 0
+        if ui_lengths is not None:
+            flat = ui_lengths.reshape(-1).cpu()
+            _, si = torch.sort(flat, descending=True)
+            n_ui = flat.numel()
+            parts += [flat, si]
+        total = 4 * N + 2 * n_ui
+        ring = cls._INDEX_RING.get(device)
+        if ring is None or ring[0][0].numel() < total:
+            ring = cls._INDEX_RING[device] = [[torch.empty(max(total, 4096), dtype=torch.int32).pin_memory() for _ in range(8)],
+                                              [None] * 8, 0]
+        k = ring[2] % 8
+        ring[2] += 1
+        if ring[1][k] is not None:
+            ring[1][k].synchronize()
+        host = ring[0][k][:total]
+        host.copy_(torch.cat(parts))        # int64 -> int32 on the host
+        devt = host.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ring[1][k] = ev
+        lens_pair, ord_pair = devt[:2 * N], devt[2 * N:4 * N]
+        lens_ui, ord_ui = (devt[4 * N:4 * N + n_ui], devt[4 * N + n_ui:]) if n_ui else (None, None)
+        return devt, lens_pair, ord_pair, lens_ui, ord_ui
+
+    def _review_params(self):
+        rn = self.review_net
+        return (*rn.r_net.gru.weights(), rn.r_net.M, rn.s_net_u.Ms, rn.s_net_u.Ws, rn.s_net_i.Ms, rn.s_net_i.Ws,
+                rn.linear_u.weight, rn.linear_i.weight)
+
+    def _control_params(self):
         cn = self.control_net
-        c_ui = cn.c_net.gru(ui_reviews.view(B * S_ui, L_ui), lui, oui, emb).view(B, S_ui * L_ui, D)
-        g_u, g_i = cn.c_net.gru(ids, lens, order, emb, split=N)
-        c_u, c_i = g_u.view(B, S * L, D), g_i.view(B, S * L, D)
-        return _Control.apply(c_ui, c_u, c_i, (B, S_ui, L_ui, S, L), cn.c_net.threshold, cn.c_net.cnn[0].weight,
-                              cn.c_net.cnn[0].bias, cn.c_net.linear[0].weight, cn.c_net.linear[0].bias, cn.s_net.Ms,
-                              cn.s_net.Ws, cn.ss_net.linear[0].weight, cn.ss_net.linear[0].bias)
+        return (*cn.c_net.gru.weights(), cn.c_net.cnn[0].weight, cn.c_net.cnn[0].bias, cn.c_net.linear[0].weight,
+                cn.c_net.linear[0].bias, cn.s_net.Ms, cn.s_net.Ws, cn.ss_net.linear[0].weight, cn.ss_net.linear[0].bias)
 
     def forward(self, user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels):
         _MODE.b16 = self.compute_dtype == "bf16" and _TEXT_BF16
@@ -790,43 +919,39 @@ class UMPR(nn.Module):
         emb = self.embedding.weight
         B, S, L = user_reviews.shape
         _, S_ui, L_ui = ui_reviews.shape
-        lu, ou = self._host_perm(u_lengths, device)
-        li, oi = self._host_perm(i_lengths, device)
+        N = B * S
+        b16_scores = self.compute_dtype == "bf16"
+        b16_gemm = b16_scores and _TEXT_BF16
         fus = self.linear_fusion[0]
-        if self.review_net_only:
-            rr = self._review(self._pair(user_reviews, item_reviews, lu, ou, li, oi), S, L, emb)
+        main = torch.cuda.current_stream(device)
+        full = not self.review_net_only
+        side = self._side_stream(device, 0) if (TEXT_STREAM and full) else None
+        if side is not None:
+            side.wait_stream(main)
+        # The text path (many small, latency-bound kernels: GRUs, co-attention, heads) runs on a side stream beside the
+        # VGG stack (MFMA-bound) and joins it at the head; autograd replays the same split in backward.
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            idx, lens, order, lens_ui, ord_ui = self._index_upload(u_lengths, i_lengths, ui_lengths if full else None, device)
+            ids_pair = torch.empty(2 * N, L, device=device, dtype=torch.int64)
+            lib().call("umpr_concat_ids", user_reviews, item_reviews, N * L, ids_pair, stream_ptr())
+            rr = _ReviewNetF.apply(ids_pair, lens, order, emb, (B, S, L), b16_gemm, b16_scores, *self._review_params())
+            if full:
+                cu, ci, pp, pn = _ControlNetF.apply(ui_reviews.view(B * S_ui, L_ui), ids_pair, lens_ui, ord_ui, lens, order, emb,
+                                                    (B, S_ui, L_ui, S, L), self.control_net.c_net.threshold, b16_gemm,
+                                                    *self._control_params())
+        if not full:
             pred, loss, terms = _Head.apply(rr, None, None, None, None, None, None, None, None, None, fus.weight,
                                             fus.bias, labels, 0.0, 0, 0)
             self.last_loss_terms = terms
             return pred, loss
-        lui, oui = self._host_perm(ui_lengths, device)
-        # The text path (many small, latency-bound kernels: GRUs, co-attention, heads) runs on a side stream beside the
-        # VGG stack (MFMA-bound) and joins it at the head; autograd replays the same split in backward.
-        main = torch.cuda.current_stream(device)
-        sides = [self._side_stream(device, 0), self._side_stream(device, 1 if TEXT_STREAMS >= 2 else 0)] if TEXT_STREAM else None
-        if sides is not None:
-            for st in set(sides):
-                st.wait_stream(main)
-            with torch.cuda.stream(sides[0]):
-                pair = self._pair(user_reviews, item_reviews, lu, ou, li, oi)
-                rr = self._review(pair, S, L, emb)
-            if sides[1] is not sides[0]:
-                sides[1].wait_stream(sides[0])
-            with torch.cuda.stream(sides[1]):
-                cu, ci, pp, pn = self._control(pair, S, L, ui_reviews, lui, oui, emb)
-            for t in (user_reviews, item_reviews, ui_reviews, lu, ou, li, oi, lui, oui):
-                for st in set(sides):
-                    t.record_stream(st)
-        else:
-            pair = self._pair(user_reviews, item_reviews, lu, ou, li, oi)
-            rr = self._review(pair, S, L, emb)
-            cu, ci, pp, pn = self._control(pair, S, L, ui_reviews, lui, oui, emb)
+        if side is not None:
+            for t in (user_reviews, item_reviews, ui_reviews, idx, ids_pair):
+                t.record_stream(side)
         vn = self.visual_net
         V, Pc = photos.shape[1], photos.shape[2]
         vgg = vn.vgg16[0](photos.reshape(B * V * Pc, *photos.shape[3:]).float())
-        if sides is not None:
-            for st in set(sides):
-                main.wait_stream(st)
+        if side is not None:
+            main.wait_stream(side)
             for t in (rr, cu, ci, pp, pn):
                 t.record_stream(main)
         pred, loss, terms = _Head.apply(rr, cu, ci, pp, pn, vgg, vn.pos_v_emb, vn.neg_v_emb, vn.linear.weight,

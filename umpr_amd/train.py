@@ -32,6 +32,17 @@ def evaluate_mse(model, dataloader):
     return se / max(cnt, 1)
 
 
+_ONES = {}
+
+
+def _one_like(loss):
+    key = (loss.device, loss.dtype)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    return t
+
+
 def train_step(model, opt: FusedAdam, batch, world=1, reducer=None):
     """model.train(); pred, loss = model(*batch); loss.mean(); zero_grad; backward; step  (main.py:32-37).
     With world > 1 the gradients are summed over ranks (RCCL) - by `reducer` overlapped with backward if given."""
@@ -63,7 +74,7 @@ def train_step(model, opt: FusedAdam, batch, world=1, reducer=None):
         # all-reduce of that slice when data parallel.  Without a reducer the exchange only happens after backward
         # (allreduce_arenas below), so the early update stays off (it would use the local gradient).
         opt.arm_early(1.0 / n_active)
-    loss.backward()
+    loss.backward(gradient=_one_like(loss))     # a cached device scalar: autograd's implicit ones_like is a fill kernel per step
     if world > 1 or reducer is not None:
         if reducer is not None:
             reducer.finish()
