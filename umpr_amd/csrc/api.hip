@@ -57,6 +57,7 @@ struct VggLayout {
   int conv_cin[13], conv_cout[13], conv_hw[13], conv_block[13];
   size_t fc_off[2];     // ReLU outputs of fc1, fc2 ([n][4096])
   size_t drop_off[2];   // dropout outputs
+  size_t v_off[13], v_floats[13];   // transformed inputs the forward keeps for the weight gradient (umpr_wino_v_floats; 0: none)
   size_t total;         // floats
 };
 VggLayout vgg_layout(int n) {
@@ -77,6 +78,14 @@ VggLayout vgg_layout(int n) {
   }
   for (int j = 0; j < 2; ++j) { L.fc_off[j] = off; off += (size_t)n * 4096; }
   for (int j = 0; j < 2; ++j) { L.drop_off[j] = off; off += (size_t)n * 4096; }
+  for (int i = 0; i < 13; ++i) {
+    // only layers whose forward takes the Winograd path (56 / 28 maps, conv2_2 at 112; the 14x14 maps' weight gradient is on
+    // the 2x2 tile and umpr_wino_v_floats returns 0 for them)
+    const bool wl = umpr_conv3x3_fwd_is_wino(L.conv_cin[i], L.conv_cout[i], L.conv_hw[i], L.conv_hw[i]);
+    L.v_floats[i] = wl ? umpr_wino_v_floats(n, L.conv_cin[i], L.conv_cout[i], L.conv_hw[i], L.conv_hw[i]) : 0;
+    L.v_off[i] = off;
+    off += L.v_floats[i];
+  }
   L.total = off;
   return L;
 }
@@ -451,8 +460,10 @@ int umpr_vgg16_features_fwd(const float* images, const float* const* params, int
       float* y = acts + L.conv_off[ci];
       const int hw = L.conv_hw[ci];
       umpr_wino_set_pool_follows(j == kConvPerBlock[b] - 1);   // the block's last convolution feeds the max-pool
+      if (L.v_floats[ci] && !umpr_wino_inference()) umpr_wino_set_v_slot(acts + L.v_off[ci], L.v_floats[ci]);
       const int rc = umpr_conv3x3_run(x, params[2 * ci], 0, params[2 * ci + 1], nullptr, y, n, L.conv_cin[ci],
                                       L.conv_cout[ci], hw, hw, 1, ws, ws_bytes / sizeof(float), s);
+      umpr_wino_set_v_slot(nullptr, 0);
       umpr_wino_set_pool_follows(0);
       if (rc) return rc;
       x = y;
@@ -691,8 +702,11 @@ int umpr_vgg16_features_bwd(const float* images, const float* const* params, int
         (void)hipEventRecord(g_wside.ready[ci], s);
         (void)hipStreamWaitEvent(sw, g_wside.ready[ci], 0);
       }
-      if (int rc = umpr_conv3x3_wgrad(g, xin, grads[2 * ci], grads[2 * ci + 1], n, cin, cout, hw, hw, 0, scratch,
-                                      slab_bytes, sw)) return rc;
+      if (L.v_floats[ci]) umpr_wino_set_v_slot(const_cast<float*>(acts) + L.v_off[ci], L.v_floats[ci]);   // written by the forward
+      const int rcw = umpr_conv3x3_wgrad(g, xin, grads[2 * ci], grads[2 * ci + 1], n, cin, cout, hw, hw, 0, scratch,
+                                         slab_bytes, sw);
+      umpr_wino_set_v_slot(nullptr, 0);
+      if (rcw) return rcw;
       if (side) {
         (void)hipEventRecord(g_wside.done[ci], sw);
         slot_reader[gslot] = ci;

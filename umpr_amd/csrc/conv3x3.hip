@@ -1093,6 +1093,17 @@ size_t umpr_conv3x3_pack_floats(int N, int Cin, int Cout, int H, int W) {
   return m;
 }
 
+// training forward of conv2_2 (128 -> 128 at 112x112): on the 4x4 tile as well since the decision fix-up exists (round 3)
+static bool fwd_wide() {
+  static const int fwd112 = umpr_env_int("UMPR_WINO_112_FWD", 1);
+  return fwd112 && umpr_wino_f4_mode() >= 2;
+}
+// does a TRAINING forward of this layer take the Winograd path (given the scratch umpr_conv3x3_pack_floats asks for)?  The VGG
+// forward keeps the transformed input of such layers for the weight gradient (umpr_wino_v_floats).
+bool umpr_conv3x3_fwd_is_wino(int Cin, int Cout, int H, int W) {
+  return (fwd_wide() ? wino_bwd_layer(Cin, Cout, H, W) : wino_layer(H, W)) && !g_conv_no_wino && !g_conv_force_v1 && Cin >= 32;
+}
+
 // Forward (transposed = 0):  y[N][Cout] = relu?(conv(x[N][Cin], w) + bias)
 // Data gradient (transposed = 1):  y[N][Cin] = conv^T(x[N][Cout], w) * [mask > 0]
 // w is always the parameter [Cout][Cin][3][3]; wpack: scratch of umpr_conv3x3_pack_floats(...) floats.
@@ -1104,10 +1115,7 @@ int umpr_conv3x3_run(const float* x, const float* w, int transposed, const float
   const int C = transposed ? Cout : Cin;   // reduction channels
   const long NP = (long)N * H * W;
   // in inference the forward pass takes what the backward pass takes (conv2_2 on the 4x4 tile as well)
-  // training forward of conv2_2 (128 -> 128 at 112x112): on the 4x4 tile as well since the decision fix-up exists (round 3)
-  static const int fwd112 = umpr_env_int("UMPR_WINO_112_FWD", 1);
-  const bool fwd_wide = fwd112 && umpr_wino_f4_mode() >= 2;
-  if ((transposed || umpr_wino_inference() || fwd_wide ? wino_bwd_layer(C, M, H, W) : wino_layer(H, W)) && !g_conv_no_wino && !g_conv_force_v1 && wpack && C >= 32 &&
+  if ((transposed || umpr_wino_inference() || fwd_wide() ? wino_bwd_layer(C, M, H, W) : wino_layer(H, W)) && !g_conv_no_wino && !g_conv_force_v1 && wpack && C >= 32 &&
       wpack_floats >= umpr_wino_ws_floats(N, C, M, H, W, transposed)) {
     // Winograd (F(2x2,3x3) forward, F(4x4,3x3) data gradient): 2.25x / 4x fewer MFMA FLOPs; timed under the same family with
     // the direct conv's FLOP count

@@ -73,6 +73,9 @@ size_t umpr_wino_ws_floats(int N, int C, int M, int H, int W, int transposed);
 void umpr_wino_set_inference(int on);   // per host thread, see umpr_set_conv_inference
 void umpr_wino_set_pool_follows(int on);   // per host thread, see umpr_set_conv_pool_follows
 long umpr_wino_last_fix_count();            // see umpr_debug_wino_fix_count
+void umpr_wino_set_v_slot(float* p, size_t floats);   // per host thread: where a training forward keeps V for the weight gradient
+size_t umpr_wino_v_floats(int N, int Cin, int Cout, int H, int W);   // 0: the layer's V is not shared
+bool umpr_conv3x3_fwd_is_wino(int Cin, int Cout, int H, int W);     // the training forward of this layer runs Winograd
 int umpr_wino_inference();
 int umpr_wino_f4_mode();   // UMPR_WINO_F4: 0 = F(2x2,3x3) only, 1 = F(4x4,3x3) in the backward pass, 2 = forward as well
 size_t umpr_wino_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W);

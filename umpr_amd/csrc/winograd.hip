@@ -997,6 +997,15 @@ static inline bool wino_f4_shape(int H, int W) {
 // like the inference hint): the decision fix-up then also covers the pool windows' argmax (see WinoFix).
 static thread_local int t_wino_pool_follows = 0;
 void umpr_wino_set_pool_follows(int on) { t_wino_pool_follows = on; }
+// V slot (round 3): the transformed input V = B^T d B of a training forward on the 4x4 tile is exactly what the weight gradient
+// of the same layer transforms again in backward (same input, same tile, same padded layout).  When the caller names a buffer
+// that outlives the forward (umpr_vgg16_features_fwd: a region of the activation arena), the forward GEMM reads its B operand
+// from there and the weight gradient skips its own input transform (seven of the ten Winograd layers qualify; ~0.9 ms of pure
+// HBM traffic per step for 2.7 GB of arena at batch 64).  Per host thread, like the other hints.
+static thread_local float* t_v_slot = nullptr;
+static thread_local size_t t_v_slot_floats = 0;
+void umpr_wino_set_v_slot(float* p, size_t floats) { t_v_slot = p; t_v_slot_floats = floats; }
+
 // test / tooling aid: the list counter of this host thread's most recent fix-up pass (device memory inside that call's workspace)
 static thread_local const unsigned int* t_last_fix_count = nullptr;
 long umpr_wino_last_fix_count() {
@@ -1045,6 +1054,19 @@ static int wino_chunk_images(int N, long floats_per_image) {
   return (N + parts - 1) / parts;
 }
 
+// floats of the forward V of a layer whose weight gradient can read it back (0: the layer does not qualify): training forward
+// and weight gradient both on the 4x4 tile over the same tile grid, and the two GEMMs' channel paddings agree
+size_t umpr_wino_v_floats(int N, int Cin, int Cout, int H, int W) {
+  if (umpr_wino_f4_mode() < 2 || !wino_f4_shape(H, W) || (H % 4) != 0 || (W % 4) != 0) return 0;
+  static const int on = umpr_env_int("UMPR_WINO_V_REUSE", 1);
+  if (!on || g_wino_chunk_mb > 0) return 0;
+  const long S = (Cin + WK - 1) / WK;
+  const long bnc = Cin <= 64 ? 64 : WBN;
+  if (S * WK != (Cin + bnc - 1) / bnc * bnc) return 0;
+  const long T = (long)N * (H / 4) * (W / 4);
+  return (size_t)36 * S * WK * wino_tpad(T);
+}
+
 static int wino_conv3x3_pass(const float* x, const float* w, int transposed, const float* bias, const float* mask, float* y,
                              int N, int Cin, int Cout, int H, int W, int relu, float* ws, size_t ws_floats, hipStream_t s,
                              bool weights_ready);
@@ -1080,6 +1102,14 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
   float* U = ws;
   float* V = U + (size_t)planes * MT * WBM * S * WK;
   float* Mx = V + (size_t)planes * S * WK * Tpad;
+  float* list_region = V;        // the fix-up list lives in the workspace's V region (free once the GEMM has read it, or at once
+                                 // when V itself lives in the caller's slot)
+  if (t_v_slot && !transposed) {
+    const size_t vfl = umpr_wino_v_floats(N, Cin, Cout, H, W);
+    UMPR_REQUIRE(f4 && !t_wino_infer && vfl > 0 && vfl == (size_t)planes * S * WK * Tpad && t_v_slot_floats >= vfl,
+                 "winograd: the V slot does not fit this forward (%d -> %d at %dx%d)", Cin, Cout, H, W);
+    V = t_v_slot;
+  }
   if (!weights_ready) {
     if (f4) wino4_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed, wino4_consts());
     else wino_weights_kernel<<<nblk((long)MT * WBM * S * WK, 2048), 256, 0, s>>>(w, U, M, C, Cin, transposed);
@@ -1098,7 +1128,7 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
   unsigned int* tie_bits = nullptr;
   if (fix) {
     fx.count = reinterpret_cast<unsigned int*>(Mx + (size_t)planes * MT * WBM * Tpad);
-    fx.list = reinterpret_cast<unsigned int*>(V);
+    fx.list = reinterpret_cast<unsigned int*>(list_region);
     const size_t vfl = (size_t)planes * S * WK * Tpad;
     fx.cap = (unsigned)(vfl < (size_t)0x7fffffff ? vfl : (size_t)0x7fffffff);
     fx.kappa_eps = (float)kappa * 5.9604644775390625e-08f;
@@ -1140,9 +1170,9 @@ static int wino_conv3x3_pass(const float* x, const float* w, int transposed, con
     if (edge) wino4_output_kernel<true, true><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu, wino4_consts(), fx);
     else wino4_output_kernel<false, true><<<nblk((long)M * T, 16384), 256, 0, s>>>(Mx, bias, mask, y, N, M, H, W, Tpad, MT * WBM, relu, wino4_consts(), fx);
     UMPR_LAUNCH_CHECK("wino_output");
-    // 2048 waves: the list is usually a few hundred outputs (most workgroups leave at once; 8192 waves cost 27 us per launch
-    // just to start and leave), each a latency-bound gather of 9 C inputs
-    wino_fixup_kernel<<<512, 256, 0, s>>>(x, w, bias, y, fx.list, fx.count, fx.cap, C, M, H, W, relu);
+    // 512 waves: the list is usually a few hundred outputs (most workgroups leave at once; 8192 waves cost 27 us per launch
+    // just to start and leave, 2048 waves 25 us), each a latency-bound gather of 9 C inputs
+    wino_fixup_kernel<<<128, 256, 0, s>>>(x, w, bias, y, fx.list, fx.count, fx.cap, C, M, H, W, relu);
     UMPR_LAUNCH_CHECK("wino_fixup");
     t_last_fix_count = fx.count;
     return 0;
@@ -1712,7 +1742,12 @@ static int wino_wgrad_pass(const float* dy, const float* x, float* dw, float* db
   else
     wino_dy_kernel<<<nblk((long)Cout * g.Tpad, 16384), 256, 0, s>>>(dy, Gy, N, Cout, H, W, g.Tpad, g.Tpad, g.Mpad);
   UMPR_LAUNCH_CHECK("wino_dy");
-  if (f4 && edge)
+  if (t_v_slot) {   // the forward pass left this layer's transformed input in the caller's slot
+    const size_t vfl = umpr_wino_v_floats(N, Cin, Cout, H, W);
+    UMPR_REQUIRE(f4 && !edge && vfl == (size_t)g.planes * g.Cpad * g.Tpad && t_v_slot_floats >= vfl,
+                 "winograd wgrad: the V slot does not match this layer (%d -> %d at %dx%d)", Cin, Cout, H, W);
+    V = t_v_slot;
+  } else if (f4 && edge)
     wino4_input_kernel<true, false><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad, wino4_consts(), nullptr, nullptr);
   else if (f4)
     wino4_input_kernel<false, false><<<nblk((long)g.Cpad * g.Tpad, 16384), 256, 0, s>>>(x, V, N, Cin, g.Cpad, H, W, g.Tpad, g.Tpad, wino4_consts(), nullptr, nullptr);
