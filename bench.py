@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--review_net_only", action="store_true")
     ap.add_argument("--realistic", action="store_true", help="ragged lengths instead of fully padded")
     ap.add_argument("--eval", action="store_true", help="forward only (evaluate.py's path): inference samples/s")
+    ap.add_argument("--fwd-train", action="store_true",
+                    help="measurement aid (tools/pmc_traffic.sh): a step is the TRAINING forward alone (grad enabled, no backward), so "
+                         "that every convolution dispatch of a counter pass is a forward launch of the algorithm training uses")
     ap.add_argument("--h2d", action="store_true",
                     help="also time a loop whose batches arrive from pinned host memory (upload double-buffered "
                          "under the previous step), reported as h2d_inclusive; `value` stays the resident figure")
@@ -205,9 +208,13 @@ def pmc_traffic(bf16=False, infer=False):
     suffix, family = ("_pmc_traffic_bf16_fwd.json", "b16_conv_family") if bf16 else ("_pmc_traffic_fwd.json", "igemm_family")
     if infer and not bf16:      # the fp32 inference forward runs the 4x4 Winograd tile: its own stored pass
         suffix = "_pmc_traffic_infer.json"
-    # newest first: record tags run r02_a .. r02_z, r02_aa .. (longer tag = later)
-    for name in sorted((f for f in os.listdir(prof) if f.endswith(suffix) and ("bf16" in f) == bf16),
-                       key=lambda f: (len(f[:-len(suffix)]), f), reverse=True):
+    # newest first: record names are r<round>_<tag>_...; within a round tags run a .. z, aa .. (longer tag = later)
+    def age(f):
+        head = f[:-len(suffix)].split("_")
+        rnd = int(head[0][1:]) if head[0][1:].isdigit() else 0
+        tag = head[1] if len(head) > 1 else ""
+        return (rnd, len(tag), tag)
+    for name in sorted((f for f in os.listdir(prof) if f.endswith(suffix) and ("bf16" in f) == bf16), key=age, reverse=True):
         try:
             d = json.load(open(os.path.join(prof, name)))
             f = d["families"][family]
@@ -384,6 +391,9 @@ def run_workload(w, env):
         torch.cuda.synchronize()
 
     def step(b=batch):
+        if getattr(w, "fwd_train", False):
+            model.train()
+            return model(*b)
         if not w.eval:
             return train_step(model, opt, b, world, reducer)
         with torch.no_grad():
@@ -528,7 +538,7 @@ def main():
         torch.cuda.set_device(dev)
         env = {"L": lib(), "dev": dev, "rank": rank, "world": world}
         out, P = run_workload(args, env)
-        default_line = (world == 1 and not args.no_other_configs and not args.eval and not args.review_net_only
+        default_line = (world == 1 and not args.no_other_configs and not args.eval and not args.fwd_train and not args.review_net_only
                         and not args.realistic and not args.h2d
                         and (args.batch, args.views, args.emb, args.dtype) == (64, 1, 50, "fp32"))
         if default_line:
@@ -550,7 +560,7 @@ def main():
                                                               "launches", "avg_launch_ms") if k in r}
             out["other_configs"] = others
         if rank == 0:
-            if world == 1 and not args.no_cpu_baseline and not args.eval:
+            if world == 1 and not args.no_cpu_baseline and not args.eval and not args.fwd_train:
                 out["cpu_baseline"] = cpu_baseline(args, P, rank)
             result_out.write(json.dumps(out) + "\n")
             result_out.flush()
