@@ -25,6 +25,19 @@ def test_model_on_cpu_raises():
         model(*make_batch(2, 2, 100, review_net_only=True))
 
 
+def test_conv_width_and_sentence_length_limits():
+    """Even C-Net kernel sizes and sentences up to 256 tokens construct (round 3); beyond the kernels' range the constructor
+    refuses instead of diverging silently."""
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_param_state
+    P = make_param_state(1, 50, 100, 1, True)
+    UMPR(_cfg(review_net_only=False, kernel_size=2, max_sent_length=200, views=["a"]), P["embedding.weight"].numpy())
+    with pytest.raises(AssertionError, match="max_sent_length"):
+        UMPR(_cfg(review_net_only=True, max_sent_length=300), P["embedding.weight"].numpy())
+    with pytest.raises(AssertionError, match="kernel_size"):
+        UMPR(_cfg(review_net_only=False, kernel_size=9, views=["a"]), P["embedding.weight"].numpy())
+
+
 def test_unsupported_hidden_size_raises():
     from umpr_amd.model import UMPR
     from umpr_amd.synthetic import make_param_state

@@ -327,7 +327,9 @@ def _text_params(seed, V, m_scale):
     return make_param_state(seed, 50, 500, V, False, with_vgg=False, m_scale=m_scale)
 
 
-@pytest.mark.parametrize("B,S,Lm,m_scale", [(3, 20, 20, 1.0), (2, 7, 9, 0.05), (5, 20, 20, 0.05)])
+@pytest.mark.parametrize("B,S,Lm,m_scale", [(3, 20, 20, 1.0), (2, 7, 9, 0.05), (5, 20, 20, 0.05),
+                                            # sentences longer than one wave (review_level='review', src/dataset.py:24)
+                                            (2, 3, 100, 0.05), (1, 2, 200, 0.3)])
 def test_review_head(L, dev, B, S, Lm, m_scale):
     from oracle import umpr_ref as R
     from umpr_amd.model import _ReviewHead
@@ -363,11 +365,16 @@ def test_review_head(L, dev, B, S, Lm, m_scale):
         check(f"review_head d{k} m{m_scale}", t.grad, P[k].grad, atol=1e-6, rel_to_max=1e-3)
 
 
-@pytest.mark.parametrize("B,S_ui,L_ui,S,Lm,V", [(3, 5, 20, 20, 20, 1), (2, 3, 11, 6, 9, 4), (4, 1, 6, 5, 20, 4)])
-def test_control(L, dev, B, S_ui, L_ui, S, Lm, V):
+@pytest.mark.parametrize("B,S_ui,L_ui,S,Lm,V,KS", [(3, 5, 20, 20, 20, 1, 3), (2, 3, 11, 6, 9, 4, 3), (4, 1, 6, 5, 20, 4, 3),
+                                                   # config.py:37's comment lists kernel sizes 1, 2, 3: an even width yields
+                                                   # L - 1 conv positions (src/model.py:93); plus sentences of 70 tokens
+                                                   (2, 3, 11, 6, 9, 2, 2), (2, 2, 7, 4, 12, 1, 1), (2, 2, 9, 3, 10, 3, 4),
+                                                   (2, 2, 70, 3, 66, 2, 3)])
+def test_control(L, dev, B, S_ui, L_ui, S, Lm, V, KS):
     from oracle import umpr_ref as R
     from umpr_amd.model import _Control
-    P = _text_params(13, V, 0.3)
+    from umpr_amd.synthetic import make_param_state
+    P = make_param_state(13, 50, 500, V, False, with_vgg=False, m_scale=0.3, kernel_size=KS)
     g = torch.Generator().manual_seed(B * 10 + V)
     gs = [(torch.randn(B, s * l, 128, generator=g) * 0.7).requires_grad_(True) for s, l in ((S_ui, L_ui), (S, Lm), (S, Lm))]
     pre = "control_net."
@@ -378,7 +385,7 @@ def test_control(L, dev, B, S_ui, L_ui, S, Lm, V):
 
     def head(x, s, l):
         cnn_in = x.reshape(B * s, l, -1).transpose(-1, -2)
-        y = F.relu(F.conv1d(cnn_in, P[keys[0]], P[keys[1]], padding=1)).max(dim=-1)[0].view(B, s, -1)
+        y = F.relu(F.conv1d(cnn_in, P[keys[0]], P[keys[1]], padding=(KS - 1) // 2)).max(dim=-1)[0].view(B, s, -1)
         vp = torch.sigmoid(F.linear(y, P[keys[2]], P[keys[3]]))
         vp = torch.where(vp < 0.35, torch.zeros_like(vp), vp)
         return vp, (vp ** 2).sum(-2)
@@ -400,12 +407,12 @@ def test_control(L, dev, B, S_ui, L_ui, S, Lm, V):
     wd = [P[k].detach().to(dev).requires_grad_(True) for k in keys]
     outs = _Control.apply(gd[0], gd[1], gd[2], (B, S_ui, L_ui, S, Lm), 0.35, *wd)
     for nm, o, r in zip(("c_u", "c_i", "prefer_pos", "prefer_neg"), outs, refs):
-        check(f"control fwd {nm} V{V}", o, r, atol=2e-5, rtol=1e-5)
+        check(f"control fwd {nm} V{V} KS{KS}", o, r, atol=2e-5, rtol=1e-5)
     torch.autograd.backward(outs, [t.to(dev) for t in gouts])
     for i in range(3):
-        check(f"control dG{i} V{V}", gd[i].grad, gs[i].grad, atol=1e-6, rel_to_max=1e-3)
+        check(f"control dG{i} V{V} KS{KS}", gd[i].grad, gs[i].grad, atol=1e-6, rel_to_max=1e-3)
     for k, t in zip(keys, wd):
-        check(f"control d{k} V{V}", t.grad, P[k].grad, atol=1e-6, rel_to_max=1e-3)
+        check(f"control d{k} V{V} KS{KS}", t.grad, P[k].grad, atol=1e-6, rel_to_max=1e-3)
 
 
 @pytest.mark.parametrize("B,V,Pc", [(5, 1, 1), (3, 4, 2), (6, 0, 0)])
@@ -694,6 +701,38 @@ def test_umpr_r_small_batches_vs_oracle(dev, B, seed):
     for k, p in model.named_parameters():
         if p.requires_grad:
             check(f"small-batch grad {k} B{B}", p.grad, P[k].grad, atol=1e-6, rel_to_max=2e-3)
+
+
+@pytest.mark.parametrize("KS,max_len", [(2, 20), (3, 90), (4, 70)])
+def test_kernel_size_and_sentence_length_surface_vs_oracle(dev, KS, max_len):
+    """config.py:29,37: `--kernel_size` 1 / 2 / 3 / 4 and a `--max_sent_length` beyond one wave, through the whole model (fused
+    text path, VGG16, head) on one sample pair against the oracle: predictions and loss 1e-4, text-path gradients 2e-3 of the
+    tensor maximum.  (gru_size / self_atte_size other than 64 remain refused: DESIGN section 6.)"""
+    from oracle import umpr_ref as R
+    from umpr_amd.config import Config
+    from umpr_amd.model import UMPR
+    from umpr_amd.synthetic import make_batch, make_param_state
+    P = make_param_state(67, 50, 700, 1, False, m_scale=0.05, kernel_size=KS)
+    batch = make_batch(68, 2, 700, 1, max_sent_count=4, min_sent_count=2, max_ui_sent_count=2, max_sent_length=max_len)
+    cfg = Config(argv=[])
+    cfg.views = ["unknown"]
+    cfg.kernel_size = KS
+    cfg.max_sent_length = max_len
+    model = UMPR(cfg, P["embedding.weight"].numpy())
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    pred, loss = model(*batch)
+    loss.backward()
+    for k, p in P.items():
+        if k != "embedding.weight":
+            p.requires_grad_(True)
+    rp, rl = R.umpr_forward(P, batch, review_net_only=False, aten=True)
+    rl.backward()
+    check(f"KS{KS} L{max_len} pred", pred, rp, atol=1e-4)
+    check(f"KS{KS} L{max_len} loss", loss, rl, atol=1e-4)
+    for k, p in model.named_parameters():
+        if p.requires_grad and "vgg16" not in k:
+            check(f"KS{KS} L{max_len} grad {k}", p.grad, P[k].grad, atol=1e-6, rel_to_max=2e-3)
 
 
 @pytest.mark.parametrize("E", [300, 7])

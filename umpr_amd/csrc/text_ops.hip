@@ -32,6 +32,9 @@ struct SnetFwdParams {
 };
 
 // one wave per sentence (B*S waves over the grid); the per-sample sum over sentences is snet_senti_kernel
+// NL = ceil(L / 64): lane l % 64 holds position l in slot l / 64 (L <= 64 * NL; the reference's max_sent_length is 20, but
+// review_level='review' makes whole reviews the "sentences", src/dataset.py:24 - supported up to 256 tokens)
+template <int NL>
 __global__ __launch_bounds__(256) void snet_pool_fwd_kernel(SnetFwdParams p, long nsent) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long sent = (long)blockIdx.x * 4 + wave;
@@ -39,27 +42,46 @@ __global__ __launch_bounds__(256) void snet_pool_fwd_kernel(SnetFwdParams p, lon
   const float w = p.Ws[lane];
   const float* X = p.X + sent * p.L * D;
   const float* U = p.U + sent * p.L * AT;
-  float e = -INFINITY;  // lane l holds e[l]
+  float e[NL];  // lane l % 64 holds e[l / 64]
+#pragma unroll
+  for (int k = 0; k < NL; ++k) e[k] = -INFINITY;
   int l = 0;
-  for (; l + 3 < p.L; l += 4) {   // four independent reductions in flight
+  for (; l + 3 < p.L; l += 4) {   // four independent reductions in flight (l .. l+3 share a slot: 64 is a multiple of 4)
     const float v0 = wave_sum(w * U[l * AT + lane]);
     const float v1 = wave_sum(w * U[(l + 1) * AT + lane]);
     const float v2 = wave_sum(w * U[(l + 2) * AT + lane]);
     const float v3 = wave_sum(w * U[(l + 3) * AT + lane]);
-    e = lane == l ? v0 : lane == l + 1 ? v1 : lane == l + 2 ? v2 : lane == l + 3 ? v3 : e;
+    const int ll = l & 63;
+#pragma unroll
+    for (int k = 0; k < NL; ++k)
+      if (k == (l >> 6)) e[k] = lane == ll ? v0 : lane == ll + 1 ? v1 : lane == ll + 2 ? v2 : lane == ll + 3 ? v3 : e[k];
   }
   for (; l < p.L; ++l) {
     const float v = wave_sum(w * U[l * AT + lane]);
-    if (lane == l) e = v;
+#pragma unroll
+    for (int k = 0; k < NL; ++k)
+      if (k == (l >> 6) && lane == (l & 63)) e[k] = v;
   }
-  const float m = wave_max(e);
-  const float ex = lane < p.L ? expf(e - m) : 0.f;
-  const float z = wave_sum(ex);
-  const float pr = ex / z;
-  if (lane < p.L) p.P[sent * p.L + lane] = pr;
+  float mx = e[0];
+#pragma unroll
+  for (int k = 1; k < NL; ++k) mx = fmaxf(mx, e[k]);
+  const float m = wave_max(mx);
+  float ex[NL], zs = 0.f;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) { ex[k] = 64 * k + lane < p.L ? expf(e[k] - m) : 0.f; zs += ex[k]; }
+  const float z = wave_sum(zs);
+  float pr[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    pr[k] = ex[k] / z;
+    if (64 * k + lane < p.L) p.P[sent * p.L + 64 * k + lane] = pr[k];
+  }
   float a0 = 0.f, a1 = 0.f;
   for (l = 0; l < p.L; ++l) {
-    const float pl = __shfl(pr, l, 64);
+    float src = pr[0];
+#pragma unroll
+    for (int k = 1; k < NL; ++k) src = (l >> 6) == k ? pr[k] : src;
+    const float pl = __shfl(src, l & 63, 64);
     a0 += pl * X[l * D + lane];
     a1 += pl * X[l * D + 64 + lane];
   }
@@ -92,6 +114,7 @@ struct SnetBwdParams {
 };
 
 // one wave per sentence; dWs_part[workgroup][64] = the four waves' partial sums in wave order
+template <int NL>
 __global__ __launch_bounds__(256) void snet_pool_bwd_kernel(SnetBwdParams p, long nsent) {
   __shared__ float part[4][AT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,24 +132,38 @@ __global__ __launch_bounds__(256) void snet_pool_bwd_kernel(SnetBwdParams p, lon
     const float dwsum = wave_sum(p.self_atte[sent * D + lane] * ds0 + p.self_atte[sent * D + 64 + lane] * ds1);
     if (p.d_word_soft)
       for (int i = lane; i < p.wl; i += 64) p.d_word_soft[sent * p.wl + i] = dwsum;
-    const float pr = lane < p.L ? p.P[sent * p.L + lane] : 0.f;
-    float dp = 0.f;  // lane l holds dp[l]
+    float pr[NL], dp[NL];  // lane l % 64 holds position l in slot l / 64
+#pragma unroll
+    for (int k = 0; k < NL; ++k) { pr[k] = 64 * k + lane < p.L ? p.P[sent * p.L + 64 * k + lane] : 0.f; dp[k] = 0.f; }
     int l = 0;
     for (; l + 3 < p.L; l += 4) {   // four independent reductions in flight
       const float v0 = wave_sum(X[l * D + lane] * g0 + X[l * D + 64 + lane] * g1);
       const float v1 = wave_sum(X[(l + 1) * D + lane] * g0 + X[(l + 1) * D + 64 + lane] * g1);
       const float v2 = wave_sum(X[(l + 2) * D + lane] * g0 + X[(l + 2) * D + 64 + lane] * g1);
       const float v3 = wave_sum(X[(l + 3) * D + lane] * g0 + X[(l + 3) * D + 64 + lane] * g1);
-      dp = lane == l ? v0 : lane == l + 1 ? v1 : lane == l + 2 ? v2 : lane == l + 3 ? v3 : dp;
+      const int ll = l & 63;
+#pragma unroll
+      for (int k = 0; k < NL; ++k)
+        if (k == (l >> 6)) dp[k] = lane == ll ? v0 : lane == ll + 1 ? v1 : lane == ll + 2 ? v2 : lane == ll + 3 ? v3 : dp[k];
     }
     for (; l < p.L; ++l) {
       const float v = wave_sum(X[l * D + lane] * g0 + X[l * D + 64 + lane] * g1);
-      if (lane == l) dp = v;
+#pragma unroll
+      for (int k = 0; k < NL; ++k)
+        if (k == (l >> 6) && lane == (l & 63)) dp[k] = v;
     }
-    const float dot = wave_sum(pr * dp);
-    const float de = pr * (dp - dot);
+    float pd = 0.f;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) pd += pr[k] * dp[k];
+    const float dot = wave_sum(pd);
+    float de[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) de[k] = pr[k] * (dp[k] - dot);
     for (l = 0; l < p.L; ++l) {
-      const float pl = __shfl(pr, l, 64), del = __shfl(de, l, 64);
+      float sp = pr[0], sd = de[0];
+#pragma unroll
+      for (int k = 1; k < NL; ++k) { sp = (l >> 6) == k ? pr[k] : sp; sd = (l >> 6) == k ? de[k] : sd; }
+      const float pl = __shfl(sp, l & 63, 64), del = __shfl(sd, l & 63, 64);
       float* dx = p.dX + (sent * p.L + l) * D;
       dx[lane] = pl * g0; dx[64 + lane] = pl * g1;
       const float u = U[l * AT + lane];
@@ -166,6 +203,7 @@ struct CnetHeadFwdParams {
   float* view_p;           // [B][S][V]
   float* final_;           // [B][V]
   int S, L, KC, V;
+  int Lout;                // valid conv positions: L + 2 pad - KS + 1 (= L for odd KS, L - 1 for even, like nn.Conv1d)
 };
 
 // one wave per sentence over the whole grid (was: one workgroup per sample walking S / 4 sentences per wave - 64
@@ -179,7 +217,7 @@ __global__ __launch_bounds__(256) void cnet_head_fwd_kernel(CnetHeadFwdParams p,
   const float* Y = p.Y + sent * p.L * p.KC;
   for (int k = lane; k < p.KC; k += 64) {
     float m = Y[k]; int a = 0;
-    for (int l = 1; l < p.L; ++l) {
+    for (int l = 1; l < p.Lout; ++l) {
       const float y = Y[l * p.KC + k];
       if (y > m) { m = y; a = l; }
     }
@@ -782,14 +820,17 @@ int umpr_adam_impl(float* p, const float* g, float* m, float* v, long n, float g
 int umpr_snet_fwd_impl(const float* X, const float* Ms, const float* Ws, const float* word_soft, int wl, int B, int S,
                        int L, float* U, float* P, float* wsum, float* self_atte, float* senti, long ld_senti,
                        hipStream_t s) {
-  UMPR_REQUIRE(L <= 64, "snet: sentence length %d > 64 unsupported", L);
+  UMPR_REQUIRE(L >= 1 && L <= 256, "snet: sentence length %d outside 1..256", L);
   UmprGemm g;
   g.A = X; g.lda = D; g.B = Ms; g.ldb = D; g.transB = true; g.C = U; g.ldc = AT; g.M = B * S * L; g.N = AT; g.K = D;
   g.act = UMPR_ACT_TANH;
   if (int rc = umpr_gemm(g, s)) return rc;
   SnetFwdParams p{X, U, Ws, word_soft, wl, P, wsum, self_atte, senti, ld_senti, S, L};
   const long nsent = (long)B * S;
-  snet_pool_fwd_kernel<<<(unsigned)((nsent + 3) / 4), 256, 0, s>>>(p, nsent);
+  const unsigned fgrid = (unsigned)((nsent + 3) / 4);
+  if (L <= 64) snet_pool_fwd_kernel<1><<<fgrid, 256, 0, s>>>(p, nsent);
+  else if (L <= 128) snet_pool_fwd_kernel<2><<<fgrid, 256, 0, s>>>(p, nsent);
+  else snet_pool_fwd_kernel<4><<<fgrid, 256, 0, s>>>(p, nsent);
   UMPR_LAUNCH_CHECK("snet_pool_fwd");
   snet_senti_kernel<<<B, D, 0, s>>>(wsum, self_atte, senti, ld_senti, S);
   UMPR_LAUNCH_CHECK("snet_senti");
@@ -809,7 +850,9 @@ int umpr_snet_bwd_impl(const float* X, const float* Ms, const float* Ws, const f
   const int nwg = (int)((nsent + 3) / 4);
   float* dPre = ws; float* dWs_part = ws + (size_t)B * S * L * AT; float* slab = dWs_part + (size_t)nwg * AT;
   SnetBwdParams p{X, U, Ws, P, wsum, self_atte, d_senti, ld_ds, d_self_atte, dX, dPre, dWs_part, d_word_soft, wl, S, L};
-  snet_pool_bwd_kernel<<<nwg, 256, 0, s>>>(p, nsent);
+  if (L <= 64) snet_pool_bwd_kernel<1><<<nwg, 256, 0, s>>>(p, nsent);
+  else if (L <= 128) snet_pool_bwd_kernel<2><<<nwg, 256, 0, s>>>(p, nsent);
+  else snet_pool_bwd_kernel<4><<<nwg, 256, 0, s>>>(p, nsent);
   UMPR_LAUNCH_CHECK("snet_pool_bwd");
   const int R = B * S * L;
   UmprGemm g;  // dX += dPre Ms
@@ -833,16 +876,19 @@ int umpr_cnet_head_fwd_impl(const float* X, const float* Wc, const float* bc, co
                             float* sp, float* view_p, float* final_, float* ws, size_t ws_bytes, hipStream_t s) {
   UMPR_REQUIRE(ws_bytes >= umpr_cnet_fwd_ws_bytes(B, S, L, KS), "cnet: workspace too small");
   const long R = (long)B * S * L;
-  UMPR_REQUIRE((KS & 1) == 1 && KC <= 512, "cnet: even kernel size %d or more than 512 filters (%d)", KS, KC);
+  // nn.Conv1d(padding=(KS-1)/2) (src/model.py:93): an even KS yields L - 1 positions; the window GEMM computes L (the last one
+  // reads one zero past the sentence) and the head takes its maximum over the valid ones
+  const int pad = (KS - 1) / 2, Lout = L + 2 * pad - KS + 1;
+  UMPR_REQUIRE(KS >= 1 && Lout >= 1 && KC <= 512, "cnet: kernel size %d on sentences of %d tokens, or more than 512 filters (%d)", KS, L, KC);
   float* Wp = ws;                                        // [KC][KS*D] in window order
   cnet_weight_order_kernel<<<nblocks((long)KC * D * KS), 256, 0, s>>>(Wc, Wp, KC, D, KS, 0, 0);
   UMPR_LAUNCH_CHECK("cnet_weight_order");
   UmprGemm g;   // Y = relu(win(X) Wp^T + bc): X read in place through the sliding window
-  g.A = X; g.lda = D; g.winA_L = L; g.winA_D = D; g.winA_pad = (KS - 1) / 2;
+  g.A = X; g.lda = D; g.winA_L = L; g.winA_D = D; g.winA_pad = pad;
   g.B = Wp; g.ldb = D * KS; g.transB = true; g.C = Y; g.ldc = KC; g.M = (int)R; g.N = KC;
   g.K = D * KS; g.bias = bc; g.bias_mode = 1; g.act = UMPR_ACT_RELU;
   if (int rc = umpr_gemm(g, s)) return rc;
-  CnetHeadFwdParams p{Y, Wl, bl, thr, cmax, argl, sp, view_p, final_, S, L, KC, V};
+  CnetHeadFwdParams p{Y, Wl, bl, thr, cmax, argl, sp, view_p, final_, S, L, KC, V, Lout};
   const long nsent = (long)B * S;
   cnet_head_fwd_kernel<<<(unsigned)((nsent + 3) / 4), 256, 4 * KC * sizeof(float), s>>>(p, nsent);
   UMPR_LAUNCH_CHECK("cnet_head_fwd");
@@ -880,7 +926,7 @@ int umpr_cnet_head_bwd_impl(const float* X, const float* Wc, const float* Wl, co
   colsum_stage2_kernel<<<cdiv(V, 64), 256, 0, s>>>(dbl_part, B, V, dbl, accumulate_w);
   UMPR_LAUNCH_CHECK("cnet_dWl");
   if (int rc = umpr_colsum(dY, R, KC, KC, dbc, accumulate_w, cs, (size_t)cdiv(R, 256) * KC * sizeof(float), s)) return rc;
-  UMPR_REQUIRE((KS & 1) == 1 && (KC & 3) == 0, "cnet_bwd: kernel size %d / %d filters", KS, KC);
+  UMPR_REQUIRE(KS >= 1 && (KC & 3) == 0, "cnet_bwd: kernel size %d / %d filters", KS, KC);
   const int pad = (KS - 1) / 2;
   UmprGemm h;  // dWp[KC][CK] = dY^T win(X)
   h.A = dY; h.lda = KC; h.transA = true; h.B = X; h.ldb = D; h.winB_L = L; h.winB_D = D; h.winB_pad = pad;
@@ -891,7 +937,9 @@ int umpr_cnet_head_bwd_impl(const float* X, const float* Wc, const float* Wl, co
   cnet_weight_order_kernel<<<nblocks((long)KC * CK), 256, 0, s>>>(Wc, Wq, KC, D, KS, 1, 0);
   UMPR_LAUNCH_CHECK("cnet_weight_order");
   UmprGemm g;  // dX (+)= win(dY) Wq: the transposed convolution, again through the window
-  g.A = dY; g.lda = KC; g.winA_L = L; g.winA_D = KC; g.winA_pad = pad;
+  // y[j] = sum_t w_t x[j + t - pad]  =>  dx[i] = sum_j' dy[i + j' - (KS - 1 - pad)] w_{KS-1-j'}: the window's pad is KS - 1 - pad
+  // (= pad for odd KS)
+  g.A = dY; g.lda = KC; g.winA_L = L; g.winA_D = KC; g.winA_pad = KS - 1 - pad;
   g.B = Wq; g.ldb = D; g.C = dX; g.ldc = D; g.M = (int)R; g.N = D; g.K = KS * KC; g.accumulate = accumulate_dX != 0;
   if (int rc = umpr_gemm(g, s)) return rc;
   return 0;

@@ -676,9 +676,9 @@ class SNet(nn.Module):
 class CNet(nn.Module):
     def __init__(self, gru_in, gru_out, k_count, k_size, view_size, threshold=0.35):
         super().__init__()
-        # the im2col of the C-Net conv emits L positions with pad (k-1)/2, which equals nn.Conv1d only for odd widths
-        # (an even k_size yields L-1 positions in the reference, src/model.py:93): refuse rather than diverge silently
-        assert k_size % 2 == 1, f"kernel_size={k_size}: the C-Net kernels implement odd Conv1d widths only (config.py:37 uses 3)"
+        # any Conv1d width: an even k_size yields L-1 positions in the reference (src/model.py:93, padding (k-1)//2), which the
+        # C-Net kernels reproduce (umpr_cnet_head_fwd: the maximum runs over the valid positions)
+        assert 1 <= k_size <= 8, f"kernel_size={k_size}: the C-Net kernels take Conv1d widths 1..8 (config.py:37 uses 3)"
         self.threshold = threshold
         self.gru = ImprovedRnn(nn.GRU, input_size=gru_in, hidden_size=gru_out, batch_first=True, bidirectional=True)
         self.cnn = nn.Sequential(nn.Conv1d(2 * gru_out, k_count, k_size, padding=(k_size - 1) // 2), nn.ReLU())
@@ -788,9 +788,9 @@ class UMPR(nn.Module):
         # stack and the co-attention scores, fp32 accumulation, fp32 master weights / GRU gates / softmax / Adam
         self.compute_dtype = str(getattr(config, "dtype", "fp32"))
         assert self.compute_dtype in ("fp32", "bf16"), f"dtype must be fp32 or bf16, got {self.compute_dtype}"
-        # one wave handles one sentence in the S-Net / C-Net kernels: at most 64 tokens per sentence (config.py:29 uses 20;
-        # review_level='review' with a longer max_sent_length would exceed it)
-        assert int(getattr(config, "max_sent_length", 20)) <= 64, "max_sent_length > 64 is not supported by the S-Net kernels"
+        # one wave handles one sentence in the S-Net kernels, up to four positions per lane: at most 256 tokens per sentence
+        # (config.py:29 uses 20; review_level='review', src/dataset.py:24, makes whole reviews the "sentences")
+        assert int(getattr(config, "max_sent_length", 20)) <= 256, "max_sent_length > 256 is not supported by the S-Net kernels"
         self.embedding = nn.Embedding.from_pretrained(torch.Tensor(word_emb))
         E = self.embedding.embedding_dim
         self.review_net = ReviewNet(E, config.gru_size, config.self_atte_size)
