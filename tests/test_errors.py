@@ -43,7 +43,10 @@ def test_unsupported_hidden_size_raises():
     from umpr_amd.synthetic import make_param_state
     P = make_param_state(1, 50, 100, 1, True)
     with pytest.raises(AssertionError, match="gru_size"):
-        UMPR(_cfg(review_net_only=True, gru_size=32), P["embedding.weight"].numpy())
+        UMPR(_cfg(review_net_only=True, gru_size=96), P["embedding.weight"].numpy())      # above the kernels' width
+    with pytest.raises(AssertionError, match="self_atte_size"):
+        UMPR(_cfg(review_net_only=True, self_atte_size=128), P["embedding.weight"].numpy())
+    UMPR(_cfg(review_net_only=True, gru_size=32, self_atte_size=48), P["embedding.weight"].numpy())   # below: embedded
 
 
 def test_missing_library_raises(monkeypatch, tmp_path):

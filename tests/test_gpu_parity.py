@@ -707,7 +707,7 @@ def test_umpr_r_small_batches_vs_oracle(dev, B, seed):
 def test_kernel_size_and_sentence_length_surface_vs_oracle(dev, KS, max_len):
     """config.py:29,37: `--kernel_size` 1 / 2 / 3 / 4 and a `--max_sent_length` beyond one wave, through the whole model (fused
     text path, VGG16, head) on one sample pair against the oracle: predictions and loss 1e-4, text-path gradients 2e-3 of the
-    tensor maximum.  (gru_size / self_atte_size other than 64 remain refused: DESIGN section 6.)"""
+    tensor maximum."""
     from oracle import umpr_ref as R
     from umpr_amd.config import Config
     from umpr_amd.model import UMPR
@@ -733,6 +733,58 @@ def test_kernel_size_and_sentence_length_surface_vs_oracle(dev, KS, max_len):
     for k, p in model.named_parameters():
         if p.requires_grad and "vgg16" not in k:
             check(f"KS{KS} L{max_len} grad {k}", p.grad, P[k].grad, atol=1e-6, rel_to_max=2e-3)
+
+
+@pytest.mark.parametrize("h,at,ronly", [(32, 64, True), (64, 32, True), (24, 40, False), (32, 32, False)])
+def test_hidden_sizes_below_the_kernel_width_vs_oracle(dev, h, at, ronly):
+    """config.py:34-35: `--gru_size` / `--self_atte_size` below 64 run EXACTLY embedded in the 64-wide kernels (units with
+    all-zero parameters stay at zero and add zero to every sum - umpr_amd/model.py::_ZeroPad); the state_dict keeps the
+    reference's shapes.  Predictions / loss 1e-4 and every text-path gradient 2e-3 of its maximum against the oracle run natively
+    at the configured sizes; one training step moves the parameters like the oracle's Adam step."""
+    from oracle import umpr_ref as R
+    from umpr_amd.config import Config
+    from umpr_amd.model import UMPR
+    from umpr_amd.optim import FusedAdam
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import train_step
+    P = make_param_state(71, 50, 700, 1, ronly, gru_size=h, atte_size=at, m_scale=0.05)
+    batch = make_batch(72, 3, 700, 1, review_net_only=ronly)
+    cfg = Config(argv=[])
+    cfg.review_net_only = ronly
+    cfg.views = ["unknown"]
+    cfg.gru_size, cfg.self_atte_size = h, at
+    model = UMPR(cfg, P["embedding.weight"].numpy())
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: tuple(v.shape) for k, v in P.items()}
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    pred, loss = model(*batch)
+    loss.backward()
+    Pr = {k: v.clone() for k, v in P.items()}
+    for k, p in Pr.items():
+        if k != "embedding.weight":
+            p.requires_grad_(True)
+    rp, rl = R.umpr_forward(Pr, batch, review_net_only=ronly, aten=True)
+    rl.backward()
+    check(f"h{h} at{at} pred", pred, rp, atol=1e-4)
+    check(f"h{h} at{at} loss", loss, rl, atol=1e-4)
+    for k, p in model.named_parameters():
+        if p.requires_grad and "vgg16" not in k:
+            check(f"h{h} at{at} grad {k}", p.grad, Pr[k].grad, atol=1e-6, rel_to_max=2e-3)
+    if ronly:      # one optimiser step through the flat arenas: the scatter / gather sits between them and the kernels
+        opt = FusedAdam(model, 1e-3, 1e-3)
+        ropt = R.adam_reference(Pr, 1e-3, 1e-3)
+        train_step(model, opt, batch)
+        _, rl2 = R.umpr_forward(Pr, batch, review_net_only=True, aten=True, train=True)
+        ropt.zero_grad()
+        rl2.backward()
+        ropt.step()
+        for k, p in model.named_parameters():
+            if p.requires_grad:
+                # Adam's first step is lr * sign(g): elements whose gradient is rounding noise around zero move by +-lr on
+                # either side at random - compare where the oracle's gradient is above that level
+                gr = Pr[k].grad
+                big = gr.abs() > 1e-4 * gr.abs().max()
+                check(f"h{h} at{at} stepped {k}", p.detach().cpu()[big], Pr[k].detach()[big], atol=2e-5, rtol=1e-4)
 
 
 @pytest.mark.parametrize("E", [300, 7])

@@ -46,6 +46,8 @@ def _grad_targets(params, can_accumulate=False):
     step (shared weights: one GRU serves several review tensors) is also updated in place.  Returns (targets, direct,
     accumulate) with ``accumulate`` true when the kernel must add; all parameters of a call share one mode."""
     def usable(p):
+        if not p.is_leaf:        # a zero-padded copy of a parameter (_ZeroPad): autograd carries its gradient back
+            return False
         g = p.grad
         return (g is not None and getattr(p, "_umpr_direct", False) and g.is_contiguous() and g.shape == p.shape
                 and g.device == p.device and g.dtype == torch.float32)
@@ -311,6 +313,53 @@ class _Control(torch.autograd.Function):
                        accw, dWc, dbc, dWl, dbl, ws, wsb, st)
         ret = _grad_returns(ctx.param_objs, tg, direct)
         return (dX_ui, dX_u, dX_i, None, None, *ret)
+
+
+# --------------------------------------------------------------------------------------------- smaller hidden sizes
+# config.gru_size / self_atte_size below the kernels' 64 (config.py:34-35 expose both; src/model.py:26-29,61-64,148-155 is generic
+# in them): the h-unit model is EXACTLY the 64-unit model whose extra units have all-zero parameters - a GRU unit with zero
+# weights and biases has r = z = 1/2, n = tanh(0) = 0 and stays at h' = z h = 0 from h0 = 0, contributes 0 to every product
+# downstream, and a sum is not changed by adding zeros.  So the reference-shaped parameters (state_dict compatible) are scattered
+# into zero tensors of the kernels' shapes on the way in (_ZeroPad: a fill and a copy, no arithmetic) and their gradients gathered
+# back on the way out; predictions, loss and gradients equal the oracle's at the configured sizes
+# (tests/test_gpu_parity.py::test_hidden_sizes_below_the_kernel_width_vs_oracle).  Costs the 64-wide work; sizes above 64 are
+# refused.
+class _ZeroPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, shape, idx0, idx1):
+        out = torch.zeros(shape, device=x.device, dtype=x.dtype)
+        if idx1 is None:
+            out.index_copy_(0, idx0, x)
+        elif idx0 is None:
+            out.index_copy_(1, idx1, x)
+        else:
+            rows = torch.zeros((x.shape[0],) + tuple(shape[1:]), device=x.device, dtype=x.dtype)
+            rows.index_copy_(1, idx1, x)
+            out.index_copy_(0, idx0, rows)
+        ctx.idx = (idx0, idx1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx0, idx1 = ctx.idx
+        if idx0 is not None:
+            g = g.index_select(0, idx0)
+        if idx1 is not None:
+            g = g.index_select(1, idx1)
+        return g, None, None, None
+
+
+class _PadMaps:
+    """Index maps from the configured sizes (h = gru_size, at = self_atte_size) into the kernels' (64, 64)."""
+
+    def __init__(self, h, at, n_views, device):
+        ar = lambda n, off=0: torch.arange(n, device=device) + off
+        self.gate = torch.cat([ar(h, q * H) for q in range(3)])            # 3h gate rows -> 192 (gate order r, z, n)
+        self.hid = ar(h)                                                    # h -> 64
+        self.rep = torch.cat([ar(h), ar(h, H)])                             # 2h ([forward; backward]) -> 128
+        self.rep2 = torch.cat([self.rep, self.rep + D])                     # [atte; senti] 4h -> 256
+        self.att = ar(at)                                                   # at -> 64
+        self.fus = torch.cat([self.rep, ar(2 * n_views, D)])                # linear_fusion input 2h (+ 2V) -> 128 (+ 2V)
 
 
 # --------------------------------------------------------------------------------------------- fused text path
@@ -645,8 +694,8 @@ class ImprovedRnn(nn.Module):
         assert module is nn.GRU, "the MI355X path implements the GRU the reference instantiates"
         super().__init__()
         self.module = module(*args, **kwargs)
-        assert self.module.hidden_size == H and self.module.bidirectional and self.module.num_layers == 1, \
-            f"kernels are built for gru_size={H} (config.py:34), bidirectional, one layer"
+        assert 1 <= self.module.hidden_size <= H and self.module.bidirectional and self.module.num_layers == 1, \
+            f"gru_size must be 1..{H} (config.py:34 uses 64: the kernels' width; smaller sizes are embedded in it), bidirectional, one layer"
 
     def weights(self):
         m = self.module
@@ -668,7 +717,8 @@ class RNet(nn.Module):
 class SNet(nn.Module):
     def __init__(self, self_atte_size, repr_size):
         super().__init__()
-        assert self_atte_size == AT and repr_size == D, f"kernels are built for self_atte_size={AT}, repr 2u={D}"
+        assert 1 <= self_atte_size <= AT and repr_size <= D, \
+            f"self_atte_size must be 1..{AT} and gru_size 1..{H} (the kernels' widths; smaller sizes are embedded in them)"
         self.Ms = nn.Parameter(torch.randn(self_atte_size, repr_size))
         self.Ws = nn.Parameter(torch.randn(1, self_atte_size))
 
@@ -791,6 +841,13 @@ class UMPR(nn.Module):
         # one wave handles one sentence in the S-Net kernels, up to four positions per lane: at most 256 tokens per sentence
         # (config.py:29 uses 20; review_level='review', src/dataset.py:24, makes whole reviews the "sentences")
         assert int(getattr(config, "max_sent_length", 20)) <= 256, "max_sent_length > 256 is not supported by the S-Net kernels"
+        self.gru_size, self.atte_size = int(config.gru_size), int(config.self_atte_size)
+        assert 1 <= self.gru_size <= H and 1 <= self.atte_size <= AT, \
+            f"gru_size={self.gru_size} / self_atte_size={self.atte_size}: the kernels are {H} / {AT} wide; smaller sizes run embedded " \
+            f"in them (exactly), larger ones are not supported"
+        self._embedded = self.gru_size != H or self.atte_size != AT
+        self._pad_maps = None
+        self.views = list(getattr(config, "views", []))
         self.embedding = nn.Embedding.from_pretrained(torch.Tensor(word_emb))
         E = self.embedding.embedding_dim
         self.review_net = ReviewNet(E, config.gru_size, config.self_atte_size)
@@ -807,10 +864,12 @@ class UMPR(nn.Module):
         # Parameters whose backward node can write the gradient straight into the optimiser's arena (_grad_targets):
         # everything in the review / control nets (GRU weights accumulate in place across their uses) and, set by VGG16
         # itself, the VGG stack; the head's own parameters (visual head, linear_fusion) by the head node.
+        # (embedded sizes: the backward nodes see zero-padded copies, and the real parameters receive their gradients through
+        # autograd's accumulation - they are zeroed and accumulated like any other torch parameter)
         for mod in (self.review_net, getattr(self, "control_net", None), self.linear_fusion):
             if mod is not None:
                 for p in mod.parameters():
-                    p._umpr_direct = True
+                    p._umpr_direct = not self._embedded
         if not config.review_net_only:
             vn = self.visual_net
             for p in (vn.pos_v_emb, vn.neg_v_emb, vn.linear.weight, vn.linear.bias):
@@ -890,15 +949,57 @@ class UMPR(nn.Module):
         lens_ui, ord_ui = (devt[4 * N:4 * N + n_ui], devt[4 * N + n_ui:]) if n_ui else (None, None)
         return devt, lens_pair, ord_pair, lens_ui, ord_ui
 
-    def _review_params(self):
-        rn = self.review_net
-        return (*rn.r_net.gru.weights(), rn.r_net.M, rn.s_net_u.Ms, rn.s_net_u.Ws, rn.s_net_i.Ms, rn.s_net_i.Ws,
-                rn.linear_u.weight, rn.linear_i.weight)
+    def _maps(self, device):
+        if self._pad_maps is None or self._pad_maps.hid.device != device:
+            self._pad_maps = _PadMaps(self.gru_size, self.atte_size, 0 if self.review_net_only else len(self.views), device)
+        return self._pad_maps
 
-    def _control_params(self):
+    def _gru_params(self, gru, device):
+        w = gru.weights()
+        if not self._embedded:
+            return w
+        m = self._maps(device)
+        E = w[0].shape[1]
+        out = []
+        for k in range(2):   # forward direction, then "_reverse"
+            wih, whh, bih, bhh = w[4 * k: 4 * k + 4]
+            out += [_ZeroPad.apply(wih, (3 * H, E), m.gate, None), _ZeroPad.apply(whh, (3 * H, H), m.gate, m.hid),
+                    _ZeroPad.apply(bih, (3 * H,), m.gate, None), _ZeroPad.apply(bhh, (3 * H,), m.gate, None)]
+        return tuple(out)
+
+    def _snet_params(self, sn, device):
+        if not self._embedded:
+            return sn.Ms, sn.Ws
+        m = self._maps(device)
+        return _ZeroPad.apply(sn.Ms, (AT, D), m.att, m.rep), _ZeroPad.apply(sn.Ws, (1, AT), None, m.att)
+
+    def _review_params(self, device=None):
+        rn = self.review_net
+        lin = (rn.linear_u.weight, rn.linear_i.weight)
+        Mx = rn.r_net.M
+        if self._embedded:
+            m = self._maps(device)
+            Mx = _ZeroPad.apply(Mx, (D, D), m.rep, m.rep)
+            lin = tuple(_ZeroPad.apply(wt, (D, 2 * D), m.rep, m.rep2) for wt in lin)
+        return (*self._gru_params(rn.r_net.gru, device), Mx, *self._snet_params(rn.s_net_u, device),
+                *self._snet_params(rn.s_net_i, device), *lin)
+
+    def _control_params(self, device=None):
         cn = self.control_net
-        return (*cn.c_net.gru.weights(), cn.c_net.cnn[0].weight, cn.c_net.cnn[0].bias, cn.c_net.linear[0].weight,
-                cn.c_net.linear[0].bias, cn.s_net.Ms, cn.s_net.Ws, cn.ss_net.linear[0].weight, cn.ss_net.linear[0].bias)
+        Wc, ssW = cn.c_net.cnn[0].weight, cn.ss_net.linear[0].weight
+        if self._embedded:
+            m = self._maps(device)
+            Wc = _ZeroPad.apply(Wc, (Wc.shape[0], D, Wc.shape[2]), None, m.rep)
+            ssW = _ZeroPad.apply(ssW, (1, D), None, m.rep)
+        return (*self._gru_params(cn.c_net.gru, device), Wc, cn.c_net.cnn[0].bias, cn.c_net.linear[0].weight,
+                cn.c_net.linear[0].bias, *self._snet_params(cn.s_net, device), ssW, cn.ss_net.linear[0].bias)
+
+    def _fusion_weight(self, device):
+        fw = self.linear_fusion[0].weight
+        if not self._embedded:
+            return fw
+        m = self._maps(device)
+        return _ZeroPad.apply(fw, (1, D + (0 if self.review_net_only else 2 * len(self.views))), None, m.fus)
 
     def forward(self, user_reviews, item_reviews, ui_reviews, u_lengths, i_lengths, ui_lengths, photos, labels):
         _MODE.b16 = self.compute_dtype == "bf16" and _TEXT_BF16
@@ -934,13 +1035,14 @@ class UMPR(nn.Module):
             idx, lens, order, lens_ui, ord_ui = self._index_upload(u_lengths, i_lengths, ui_lengths if full else None, device)
             ids_pair = torch.empty(2 * N, L, device=device, dtype=torch.int64)
             lib().call("umpr_concat_ids", user_reviews, item_reviews, N * L, ids_pair, stream_ptr())
-            rr = _ReviewNetF.apply(ids_pair, lens, order, emb, (B, S, L), b16_gemm, b16_scores, *self._review_params())
+            rr = _ReviewNetF.apply(ids_pair, lens, order, emb, (B, S, L), b16_gemm, b16_scores, *self._review_params(device))
             if full:
                 cu, ci, pp, pn = _ControlNetF.apply(ui_reviews.view(B * S_ui, L_ui), ids_pair, lens_ui, ord_ui, lens, order, emb,
                                                     (B, S_ui, L_ui, S, L), self.control_net.c_net.threshold, b16_gemm,
-                                                    *self._control_params())
+                                                    *self._control_params(device))
+        fus_w = self._fusion_weight(device)
         if not full:
-            pred, loss, terms = _Head.apply(rr, None, None, None, None, None, None, None, None, None, fus.weight,
+            pred, loss, terms = _Head.apply(rr, None, None, None, None, None, None, None, None, None, fus_w,
                                             fus.bias, labels, 0.0, 0, 0)
             self.last_loss_terms = terms
             return pred, loss
@@ -955,6 +1057,6 @@ class UMPR(nn.Module):
             for t in (rr, cu, ci, pp, pn):
                 t.record_stream(main)
         pred, loss, terms = _Head.apply(rr, cu, ci, pp, pn, vgg, vn.pos_v_emb, vn.neg_v_emb, vn.linear.weight,
-                                        vn.linear.bias, fus.weight, fus.bias, labels, self.loss_v_rate, V, Pc)
+                                        vn.linear.bias, fus_w, fus.bias, labels, self.loss_v_rate, V, Pc)
         self.last_loss_terms = terms
         return pred, loss
