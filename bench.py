@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--h2d", action="store_true",
                     help="also time a loop whose batches arrive from pinned host memory (upload double-buffered "
                          "under the previous step), reported as h2d_inclusive; `value` stays the resident figure")
+    ap.add_argument("--graph", action="store_true",
+                    help="UMPR-R only: the training step as one captured hipGraph launch (umpr_amd/graphs.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default invocation only: skip the `other_configs` sub-lines (bf16 GloVe-300d, UMPR-R, 4 views, inference)")
@@ -390,7 +392,14 @@ def run_workload(w, env):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graphed = None
+    if getattr(w, "graph", False) and w.review_net_only and not w.eval and not parallel.active():
+        from umpr_amd.graphs import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, batch)
+
     def step(b=batch):
+        if graphed is not None:
+            return graphed(b)
         if getattr(w, "fwd_train", False):
             model.train()
             return model(*b)
@@ -410,7 +419,7 @@ def run_workload(w, env):
     t0 = time.perf_counter()
     for _ in range(w.steps):
         _, loss = step()
-        losses.append(loss.detach())
+        losses.append(loss.detach().clone() if graphed is not None else loss.detach())   # a replayed graph rewrites its outputs
     t_issue = time.perf_counter() - t0        # host time to ENQUEUE the steps (no wait): close to dt => host-bound
     barrier()
     dt_local = dt = time.perf_counter() - t0
@@ -476,6 +485,8 @@ def run_workload(w, env):
         "host_issue_ms_per_step": 1e3 * t_issue / w.steps,
         "rccl_ranks": rccl_ranks, "ms_per_step_per_rank": per_rank_ms,
     }
+    if graphed is not None:
+        out["hip_graph"] = "the whole training step (forward, backward, Adam) is one captured hipGraph launch per step"
     if parallel.active():
         out["comm"] = {"backend": torch.distributed.get_backend(),
                        "exchange": ("in-stream" if (reducer is not None and reducer.comm is not None) else "async")}
@@ -507,6 +518,7 @@ def run_workload(w, env):
 OTHER_CONFIGS = (
     ("configs[4]_per_gpu_bf16_glove300_b64", dict(dtype="bf16", emb=300, batch=64)),
     ("configs[0]_umpr_r_b32", dict(review_net_only=True, batch=32)),
+    ("configs[0]_umpr_r_b32_hipgraph", dict(review_net_only=True, batch=32, graph=True)),
     ("configs[3]_per_gpu_4views_b32", dict(views=4, batch=32)),
     ("configs[3]_per_gpu_4views_b32_bf16", dict(views=4, batch=32, dtype="bf16")),
     ("inference_fp32_b64", dict(eval=True)),

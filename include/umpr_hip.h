@@ -323,6 +323,12 @@ int umpr_bce_head_bwd(const float* att, long ld, const float* w, const float* re
 int umpr_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, long step, double grad_scale, void* stream);
 
+/* The same step with its per-step scalars in DEVICE memory - hyper[4] = {grad_scale, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t),
+ * weight_decay} in the kernel's fp32 - so that a captured hipGraph of a training step can be replayed while t advances: the
+ * host refreshes the four floats before each replay (umpr_amd/graphs.py). */
+int umpr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, double beta1, double beta2, double eps,
+                       const float* hyper, void* stream);
+
 /* ---- evaluate_mse (src/evaluate.py:12-13, `mse_loss(pred, labels, reduction='sum')` accumulated over batches) -----
  * acc[0] += sum_i (pred[i] - label[i])^2, acc[1] += n; acc = two device doubles the caller zeroed once and reads back
  * once after the last batch (the reference's `.item()` per batch is a host sync per batch). */

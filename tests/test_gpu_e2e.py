@@ -384,3 +384,40 @@ def test_cfg4_full_size_forward_vs_oracle_and_backward_properties(dev):
         rp, rl = R.umpr_forward(P, batch, review_net_only=False, aten=True)
     assert float((p1.cpu() - rp).abs().max()) < 1e-4, float((p1.cpu() - rp).abs().max())
     assert abs(float(l1) - float(rl)) < 1e-4
+
+
+def test_graphed_umpr_r_step_equals_eager(dev):
+    """umpr_amd/graphs.py: the UMPR-R training step captured once as a hipGraph and replayed on four different batches of one
+    geometry leaves parameters and Adam moments BIT-identical to four eager train_step calls from the same start (the Adam
+    kernel's per-step scalars come from device memory in both runs' arithmetic), and returns the same losses."""
+    from umpr_amd.graphs import GraphedTrainStep
+    from umpr_amd.model import UMPR
+    from umpr_amd.optim import FusedAdam
+    from umpr_amd.synthetic import make_batch, make_param_state
+    from umpr_amd.train import train_step
+    P = make_param_state(21, 50, 900, 1, True, m_scale=0.05)
+    batches = [make_batch(30 + k, 6, 900, review_net_only=True, full_pad=True) for k in range(4)]
+    for b in batches[1:]:       # ragged lengths inside a fixed padded geometry: what the graph's index buffer carries
+        b[3][:, -2:] = torch.randint(3, 20, b[3][:, -2:].shape)
+    res = {}
+    for mode in ("eager", "graph"):
+        model = UMPR(_cfg(review_net_only=True), P["embedding.weight"].numpy())
+        model.load_state_dict(P)
+        model = model.to(dev)
+        opt = FusedAdam(model, 1e-3, 1e-3)
+        losses = []
+        if mode == "graph":
+            g = GraphedTrainStep(model, opt, batches[0])
+            for b in batches:
+                losses.append(float(g(b)[1]))
+        else:
+            for b in batches:
+                losses.append(float(train_step(model, opt, b)[1]))
+        assert opt.step_count == 4
+        res[mode] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, [x.m.clone() for x in opt.groups],
+                     [x.v.clone() for x in opt.groups])
+    assert res["eager"][0] == res["graph"][0], (res["eager"][0], res["graph"][0])
+    for k in res["eager"][1]:
+        assert torch.equal(res["eager"][1][k], res["graph"][1][k]), k
+    for a, b in zip(res["eager"][2] + res["eager"][3], res["graph"][2] + res["graph"][3]):
+        assert torch.equal(a, b)

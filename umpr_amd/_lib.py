@@ -100,6 +100,7 @@ SIGNATURES = {
     "umpr_bce_head_bwd": ("plpppppiiplpppzp", "i"),
     "umpr_adam_step": ("ppppldddddldp", "i"),
     "umpr_sq_err_accumulate": ("pplpp", "i"),
+    "umpr_adam_step_dev": ("pppplddd" "pp", "i"),
     "umpr_debug_poison_lds": ("pp", "i"),
     "umpr_set_gemm_bf16": ("i", "i"),
     "umpr_set_conv_inference": ("i", "i"),

@@ -1054,6 +1054,13 @@ int umpr_adam_step(float* p, const float* g, float* m, float* v, long n, double 
                         (float)step_size, (float)inv_bc2_sqrt, S(stream));
 }
 
+int umpr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, double beta1, double beta2, double eps,
+                       const float* hyper, void* stream) {
+  UMPR_REQUIRE(n >= 0 && hyper != nullptr, "adam_dev: bad arguments");
+  if (n == 0) return 0;
+  return umpr_adam_dev_impl(p, g, m, v, n, (float)beta1, (float)beta2, (float)eps, hyper, S(stream));
+}
+
 int umpr_sq_err_accumulate(const float* pred, const float* label, long n, double* acc, void* stream) {
   UMPR_REQUIRE(n >= 0 && acc != nullptr && (n == 0 || (pred != nullptr && label != nullptr)), "sq_err_accumulate: null argument");
   if (n == 0) return 0;

@@ -809,6 +809,28 @@ int umpr_sq_err_accumulate_impl(const float* pred, const float* label, long n, d
   UMPR_LAUNCH_CHECK("sq_err_accumulate");
   return 0;
 }
+// The same update with its per-step scalars read from DEVICE memory (hyper[0..3] = grad_scale, step_size = lr / (1 - b1^t),
+// 1 / sqrt(1 - b2^t), weight_decay as the caller will use them for the NEXT launch): what a captured hipGraph of a training step
+// launches - the node's kernel arguments are frozen at capture, the bias corrections change every step.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long n, float b1, float b2, float eps, const float* __restrict__ hyper) {
+  const float gscale = hyper[0], step_size = hyper[1], inv_bc2_sqrt = hyper[2], wd = hyper[3];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float gi = g[i] * gscale + wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+int umpr_adam_dev_impl(float* p, const float* g, float* m, float* v, long n, float b1, float b2, float eps, const float* hyper,
+                       hipStream_t s) {
+  adam_dev_kernel<<<nblocks(n, 8192), 256, 0, s>>>(p, g, m, v, n, b1, b2, eps, hyper);
+  UMPR_LAUNCH_CHECK("adam_dev");
+  return 0;
+}
 int umpr_adam_impl(float* p, const float* g, float* m, float* v, long n, float gscale, float wd, float b1, float b2,
                    float eps, float step_size, float inv_bc2_sqrt, hipStream_t s) {
   adam_kernel<<<nblocks(n, 8192), 256, 0, s>>>(p, g, m, v, n, gscale, wd, b1, b2, eps, step_size, inv_bc2_sqrt);

@@ -163,6 +163,8 @@ int umpr_bce_head_bwd_impl(const float* att, long ld, const float* w, const floa
 int umpr_adam_impl(float* p, const float* g, float* m, float* v, long n, float gscale, float wd, float b1, float b2,
                    float eps, float step_size, float inv_bc2_sqrt, hipStream_t s);
 int umpr_sq_err_accumulate_impl(const float* pred, const float* label, long n, double* acc, hipStream_t s);
+int umpr_adam_dev_impl(float* p, const float* g, float* m, float* v, long n, float b1, float b2, float eps, const float* hyper,
+                       hipStream_t s);
 int umpr_snet_fwd_impl(const float* X, const float* Ms, const float* Ws, const float* word_soft, int wl, int B, int S,
                        int L, float* U, float* P, float* wsum, float* self_atte, float* senti, long ld_senti,
                        hipStream_t s);

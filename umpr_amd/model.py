@@ -847,6 +847,7 @@ class UMPR(nn.Module):
             f"in them (exactly), larger ones are not supported"
         self._embedded = self.gru_size != H or self.atte_size != AT
         self._pad_maps = None
+        self._static_index = None
         self.views = list(getattr(config, "views", []))
         self.embedding = nn.Embedding.from_pretrained(torch.Tensor(word_emb))
         E = self.embedding.embedding_dim
@@ -931,6 +932,8 @@ class UMPR(nn.Module):
             n_ui = flat.numel()
             parts += [flat, si]
         total = 4 * N + 2 * n_ui
+        if device is None:           # host part only (umpr_amd/graphs.py copies it into its static buffer)
+            return torch.cat(parts).to(torch.int32), N, n_ui
         ring = cls._INDEX_RING.get(device)
         if ring is None or ring[0][0].numel() < total:
             ring = cls._INDEX_RING[device] = [[torch.empty(max(total, 4096), dtype=torch.int32).pin_memory() for _ in range(8)],
@@ -1032,7 +1035,10 @@ class UMPR(nn.Module):
         # The text path (many small, latency-bound kernels: GRUs, co-attention, heads) runs on a side stream beside the
         # VGG stack (MFMA-bound) and joins it at the head; autograd replays the same split in backward.
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            idx, lens, order, lens_ui, ord_ui = self._index_upload(u_lengths, i_lengths, ui_lengths if full else None, device)
+            if self._static_index is not None:      # a captured step (umpr_amd/graphs.py): the caller refreshed this buffer
+                idx, lens, order, lens_ui, ord_ui = self._static_index
+            else:
+                idx, lens, order, lens_ui, ord_ui = self._index_upload(u_lengths, i_lengths, ui_lengths if full else None, device)
             ids_pair = torch.empty(2 * N, L, device=device, dtype=torch.int64)
             lib().call("umpr_concat_ids", user_reviews, item_reviews, N * L, ids_pair, stream_ptr())
             rr = _ReviewNetF.apply(ids_pair, lens, order, emb, (B, S, L), b16_gemm, b16_scores, *self._review_params(device))

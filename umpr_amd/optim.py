@@ -144,6 +144,33 @@ class FusedAdam:
                 remove_callback(m, self._on_classifier_grads)
         self._early = self._early_done = None
 
+    # ---- hipGraph support: the Adam kernel's per-step scalars live in device memory (umpr_adam_step_dev) --------------------
+    def enable_graph_mode(self):
+        """From now on step() launches the device-scalar form of the kernel; prepare_step() must run before every step (eager or
+        replayed) to refresh the scalars for the step about to be taken.  The update is bit-identical to the plain form."""
+        dev = self.groups[0].p.device
+        self._hyper = torch.zeros(len(self.groups), 4, device=dev, dtype=torch.float32)
+        self._hyper_host = [torch.zeros(len(self.groups), 4, dtype=torch.float32).pin_memory() for _ in range(8)]
+        self._hyper_ev = [None] * 8
+        self._hyper_k = 0
+
+    def prepare_step(self, grad_scale=1.0):
+        t = self.step_count + 1
+        k = self._hyper_k % 8
+        self._hyper_k += 1
+        if self._hyper_ev[k] is not None:
+            self._hyper_ev[k].synchronize()
+        h = self._hyper_host[k]
+        for gi, g in enumerate(self.groups):
+            h[gi, 0] = float(grad_scale)
+            h[gi, 1] = float(self.lr / (1.0 - self.betas[0] ** t))
+            h[gi, 2] = float(1.0 / (1.0 - self.betas[1] ** t) ** 0.5)
+            h[gi, 3] = float(g.weight_decay)
+        self._hyper.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self._hyper.device))
+        self._hyper_ev[k] = ev
+
     def zero_grad(self):
         for g in self.groups:
             for lo, hi in g.zero_ranges:
@@ -221,7 +248,10 @@ class FusedAdam:
                 ranges = [(0, lo), (hi, g.numel)]
                 torch.cuda.current_stream(g.p.device).wait_event(ev)
             for lo, hi in ranges:
-                if hi > lo:
+                if hi > lo and getattr(self, "_hyper", None) is not None:
+                    lib().call("umpr_adam_step_dev", g.p[lo:hi], g.g[lo:hi], g.m[lo:hi], g.v[lo:hi], hi - lo, self.betas[0],
+                               self.betas[1], self.eps, self._hyper[gi], stream_ptr())
+                elif hi > lo:
                     lib().call("umpr_adam_step", g.p[lo:hi], g.g[lo:hi], g.m[lo:hi], g.v[lo:hi], hi - lo, self.lr,
                                self.betas[0], self.betas[1], self.eps, g.weight_decay, self.step_count, grad_scale,
                                stream_ptr())
