@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf1
 // (MI355X_MICROARCH.md, "Two waves per SIMD").  Ring safety: a stage is overwritten one full step after its last read and
 // every wave's reads are drained (lgkmcnt(0)) before the barrier that ends its load phase.
 template <int W, int TR, int TC, int BN, int WP, int WC, int D = 3, bool PP = false>
-__global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? 2 : 1)) void conv_bf16_m16_kernel(ConvB16Params p) {
+__global__ __launch_bounds__(64 * WP * WC, (WP * WC == 4 ? (TR == 4 ? 3 : 2) : 1)) void conv_bf16_m16_kernel(ConvB16Params p) {
   constexpr int ABL = 0;
   static_assert(!PP || WP * WC == 8, "ping-pong needs two waves per SIMD in one workgroup");
   constexpr int NW = WP * WC, NT = 64 * NW;
@@ -1320,6 +1320,9 @@ const int g_b16_cfg = umpr_env_int("UMPR_B16_CFG", 0);
 // UMPR_B16_T64=1: the 64-channel output tiles of the 224 / 112 maps take 512 pixels (8 waves, one workgroup per CU) instead of
 // 256 (4 waves, two per CU): half the weight re-reads from L2 per output pixel (A/B)
 const int g_b16_t64 = umpr_env_int("UMPR_B16_T64", 0);
+// UMPR_B16_T3=1: conv1_2 (64 -> 64 at 224x224, K = 576: a workgroup lives for 18 steps) on 4 x 32 = 128-pixel tiles - 48 KB of
+// LDS and <= 170 registers, THREE workgroups per CU, so that two others' main loops cover one's prologue / epilogue (A/B)
+const int g_b16_t3 = umpr_env_int("UMPR_B16_T3", 0);
 
 int conv_bn_for(int M, int W) {
   if (M % 256 == 0 && W != 14 && g_b16_cfg == 0) return 256;
@@ -1340,6 +1343,9 @@ int dispatch_conv_w(const ConvB16Params& p, hipStream_t s) {
   else if (BN == 128 && p.M % 256 == 0 && W != 14 && g_b16_cfg == 2) launch_conv<W, TR2, TC2, 128, 4, 2>(p, s);
   else if (BN == 128) launch_conv<W, TR, TC, 128, 4, 2>(p, s);
   else if (p.M % 64 == 0 && g_b16_t64 && TR2 > 0) launch_conv<W, TR2, TC2, 64, 8, 1>(p, s);   // 512-pixel tiles, 8 waves
+  else if (p.M % 64 == 0 && W == 224 && g_b16_t3) {   // 128-pixel tiles, three workgroups per CU
+    if constexpr (W == 224) launch_conv<224, 4, 32, 64, 4, 1>(p, s);
+  }
   else if (p.M % 64 == 0) launch_conv<W, TR, TC, 64, 4, 1>(p, s);
   else return -1;
   return 0;
