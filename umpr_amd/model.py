@@ -22,7 +22,8 @@ from . import _lib as _lib_mod
 from ._lib import Workspace, lib, stream_ptr
 
 TEXT_STREAM = os.environ.get("UMPR_TEXT_STREAM", "1") != "0"   # text path on side streams beside the VGG stack
-TEXT_STREAMS = int(os.environ.get("UMPR_TEXT_STREAMS", "1"))    # 2: ReviewNet and ControlNet on streams of their own - measured SLOWER (14.9 vs 12.0 ms): with the wgrad and optimiser streams that makes five, more than the hardware queues ROCm maps streams onto, and two of them serialise
+# (UMPR_TEXT_STREAMS=2 - ReviewNet and ControlNet on streams of their own - measured slower in round 2 and went away with the fused
+# text path of round 3: both are issued back to back on the one side stream)
 _SIDE_STREAMS = {}
 H = 64          # config.gru_size the kernels are built for
 D = 2 * H
