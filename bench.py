@@ -23,6 +23,11 @@ launch stream inside the timed region (libumpr_hip's umpr_profile_*):
   UMPR-R          : the recurrent GRU kernels (HBM / latency bound), algorithmic bytes / time against 8 TB/s.
 `cpu_baseline` times the oracle (oracle/umpr_ref.py, the CPU restatement pinned to the reference) on this box's host
 cores for a bounded sample.
+A default invocation (no workload flag, one GPU) also runs the other single-GPU workloads BASELINE.json names and reports them
+under `other_configs` (bf16 GloVe-300d batch 64 with its own roofline, UMPR-R batch 32 eager and as one hipGraph launch per step,
+4 views x 32 samples in fp32 and bf16, inference fp32 / bf16): 8 timed steps each; `--no-other-configs` skips them.
+`python bench.py --gpus N` without a launcher starts N workers, ends all of them when one dies and retries once with the async
+form of the gradient exchange if the in-stream form failed (spawn_workers).
 """
 import argparse
 import ctypes
