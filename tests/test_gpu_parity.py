@@ -157,6 +157,26 @@ def test_conv3x3(L, dev, N, Cin, Cout, HW):
     check(f"conv bgrad {N},{Cin},{Cout},{HW}", db, b.grad, atol=1e-4, rtol=1e-4, rel_to_max=1e-5)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,HW", [(1, 64, 128, 112), (2, 128, 128, 112), (2, 256, 256, 56), (3, 512, 512, 14)])
+def test_conv3x3_forward_under_inference(L, dev, N, Cin, Cout, HW):
+    """Under umpr_set_conv_inference(1) (what VGG16.forward sets under torch.no_grad()) the forward takes the F(4x4,3x3) tile
+    wherever the map allows, conv2_1 (64 -> 128 @112) included - a layer the training forward keeps on the direct kernel
+    (conv3x3.hip: wino_fwd_c21).  Bound: the 4x4 tile's 5e-6 of max|y| on top of 2e-5 absolute, against torch CPU fp32."""
+    g = torch.Generator().manual_seed(N + Cin + Cout + HW + 1)
+    x = torch.randn(N, Cin, HW, HW, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    y_ref = F.relu(F.conv2d(x, w, b, padding=1))
+    y = torch.full(y_ref.shape, float("nan"), device=dev)
+    wt = torch.empty(L.size("umpr_conv3x3_pack_bytes", N, Cin, Cout, HW, HW) // 4, device=dev)
+    L.call("umpr_set_conv_inference", 1)
+    try:
+        L.call("umpr_conv3x3_fwd", x.to(dev), w.to(dev), b.to(dev), y, N, Cin, HW, HW, Cout, 1, wt, wt.numel() * 4, st())
+    finally:
+        L.call("umpr_set_conv_inference", 0)
+    check(f"conv fwd (inference) {N},{Cin},{Cout},{HW}", y, y_ref, atol=2e-5, rtol=1e-5, rel_to_max=5e-6)
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 def test_conv3x3_winograd_modes(mode):
     """UMPR_WINO_F4=0 keeps every Winograd layer on F(2x2,3x3) (tight 2e-5 absolute bound everywhere); =1 is the round-2
