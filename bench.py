@@ -401,6 +401,7 @@ def run_workload(w, env):
     if getattr(w, "graph", False) and w.review_net_only and not w.eval and not parallel.active():
         from umpr_amd.graphs import GraphedTrainStep
         graphed = GraphedTrainStep(model, opt, batch)
+        batch = graphed.resident(batch)      # "batch resident in HBM": its ids / labels live where the graph reads them
 
     def step(b=batch):
         if graphed is not None:

@@ -400,24 +400,32 @@ def test_graphed_umpr_r_step_equals_eager(dev):
     for b in batches[1:]:       # ragged lengths inside a fixed padded geometry: what the graph's index buffer carries
         b[3][:, -2:] = torch.randint(3, 20, b[3][:, -2:].shape)
     res = {}
-    for mode in ("eager", "graph"):
+    def on_dev(b):       # ids / photos / labels on the device, lengths on the host (src/model.py:18)
+        return (b[0].to(dev), b[1].to(dev), b[2].to(dev), b[3], b[4], b[5], b[6].to(dev), b[7].to(dev))
+    for mode in ("eager", "graph", "graph_dev"):
         model = UMPR(_cfg(review_net_only=True), P["embedding.weight"].numpy())
         model.load_state_dict(P)
         model = model.to(dev)
         opt = FusedAdam(model, 1e-3, 1e-3)
         losses = []
-        if mode == "graph":
+        if mode == "graph":              # host batches: one packed upload per step
             g = GraphedTrainStep(model, opt, batches[0])
             for b in batches:
                 losses.append(float(g(b)[1]))
+        elif mode == "graph_dev":        # device batches: copies into the step buffer; the last one lives in it (resident())
+            g = GraphedTrainStep(model, opt, on_dev(batches[0]))
+            for b in batches[:3]:
+                losses.append(float(g(on_dev(b))[1]))
+            losses.append(float(g(g.resident(on_dev(batches[3])))[1]))
         else:
             for b in batches:
                 losses.append(float(train_step(model, opt, b)[1]))
         assert opt.step_count == 4
         res[mode] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, [x.m.clone() for x in opt.groups],
                      [x.v.clone() for x in opt.groups])
-    assert res["eager"][0] == res["graph"][0], (res["eager"][0], res["graph"][0])
-    for k in res["eager"][1]:
-        assert torch.equal(res["eager"][1][k], res["graph"][1][k]), k
-    for a, b in zip(res["eager"][2] + res["eager"][3], res["graph"][2] + res["graph"][3]):
-        assert torch.equal(a, b)
+    for mode in ("graph", "graph_dev"):
+        assert res["eager"][0] == res[mode][0], (mode, res["eager"][0], res[mode][0])
+        for k in res["eager"][1]:
+            assert torch.equal(res["eager"][1][k], res[mode][1][k]), (mode, k)
+        for a, b in zip(res["eager"][2] + res["eager"][3], res[mode][2] + res[mode][3]):
+            assert torch.equal(a, b), mode

@@ -385,6 +385,30 @@ def test_review_head(L, dev, B, S, Lm, m_scale):
         check(f"review_head d{k} m{m_scale}", t.grad, P[k].grad, atol=1e-6, rel_to_max=1e-3)
 
 
+@pytest.mark.parametrize("B", [1, 5, 32, 33, 64, 130, 256, 300])
+def test_review_merge(L, dev, B):
+    """tanh(linear_u(repr_u) + linear_i(repr_i)) (src/model.py:150-158) through umpr_review_merge_fwd / _bwd against torch fp32 on
+    the CPU: the dedicated batch-sized kernels up to B = 256 (row / workgroup boundaries at 4, 32, 128), the GEMM route above."""
+    g = torch.Generator().manual_seed(B)
+    ru = torch.randn(B, 256, generator=g).requires_grad_(True)
+    ri = torch.randn(B, 256, generator=g).requires_grad_(True)
+    Wu = (torch.randn(128, 256, generator=g) / 16).requires_grad_(True)
+    Wi = (torch.randn(128, 256, generator=g) / 16).requires_grad_(True)
+    ref = torch.tanh(F.linear(ru, Wu) + F.linear(ri, Wi))
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    d = [t.detach().to(dev) for t in (ru, ri, Wu, Wi)]
+    out = torch.full((B, 128), float("nan"), device=dev)
+    L.call("umpr_review_merge_fwd", *d, B, out, st())
+    check(f"merge fwd B{B}", out, ref, atol=2e-6)
+    wsb = L.size("umpr_review_merge_bwd_ws_bytes", B)
+    ws = torch.empty(wsb // 4 + 64, device=dev)
+    grads = [torch.full(t.shape, float("nan"), device=dev) for t in d]
+    L.call("umpr_review_merge_bwd", *d, out, gout.to(dev), B, *grads, ws, ws.numel() * 4, st())
+    for name, got, want in zip(("d_repr_u", "d_repr_i", "dW_u", "dW_i"), grads, (ru.grad, ri.grad, Wu.grad, Wi.grad)):
+        check(f"merge {name} B{B}", got, want, atol=1e-6, rel_to_max=2e-6)
+
+
 @pytest.mark.parametrize("B,S_ui,L_ui,S,Lm,V,KS", [(3, 5, 20, 20, 20, 1, 3), (2, 3, 11, 6, 9, 4, 3), (4, 1, 6, 5, 20, 4, 3),
                                                    # config.py:37's comment lists kernel sizes 1, 2, 3: an even width yields
                                                    # L - 1 conv positions (src/model.py:93); plus sentences of 70 tokens

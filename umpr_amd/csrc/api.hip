@@ -21,6 +21,8 @@ void umpr_set_error(const char* fmt, ...) {
 namespace {
 // UMPR_FC_SMALL=0: batch-sized-M products stay on the tiled GEMM (A/B runs)
 const bool g_fc_small = umpr_env_on("UMPR_FC_SMALL");
+// UMPR_MERGE_SMALL=0: linear_u / linear_i of the review merge on the fc kernels above (two launches forward, five backward)
+const bool g_merge_small = umpr_env_on("UMPR_MERGE_SMALL");
 struct ProfRec { hipEvent_t e0, e1; int family; double work; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -309,6 +311,7 @@ int umpr_snet_bwd(const float* X, const float* Ms, const float* Ws, const float*
 // ------------------------------------------------------------------------------------------------ merge
 int umpr_review_merge_fwd(const float* repr_u, const float* repr_i, const float* W_u, const float* W_i, int B,
                           float* out, void* stream) {
+  if (g_merge_small && B <= 256) return umpr_review_merge_fwd_impl(repr_u, repr_i, W_u, W_i, B, out, nullptr, S(stream));
   if (g_fc_small && umpr_fc_small_ok(B, D, 2 * D)) {
     // batch-sized M: the register-streaming kernels (no LDS stage, no barrier per k-tile) instead of one workgroup of
     // the tiled GEMM walking 16 k-tiles one global round trip at a time (35 us -> 4 us at B = 32)
@@ -326,6 +329,8 @@ int umpr_review_merge_bwd(const float* repr_u, const float* repr_i, const float*
                           const float* out, const float* d_out, int B, float* d_repr_u, float* d_repr_i, float* dW_u,
                           float* dW_i, float* ws, size_t ws_bytes, void* stream) {
   UMPR_REQUIRE(ws_bytes >= umpr_review_merge_bwd_ws_bytes(B), "review_merge_bwd: workspace too small");
+  if (g_merge_small && B <= 256)   // tanh' folded into the two kernels
+    return umpr_review_merge_bwd_impl(repr_u, repr_i, W_u, W_i, out, d_out, B, d_repr_u, d_repr_i, dW_u, dW_i, S(stream));
   float* dpre = ws;
   if (int rc = umpr_tanh_bwd(out, d_out, dpre, (long)B * D, S(stream))) return rc;
   const float* reprs[2] = {repr_u, repr_i};

@@ -344,6 +344,12 @@ __global__ __launch_bounds__(256) void gru_fwd16_kernel(GruFwdParams p) {
     hreg[r] = 0.f;
     nreg[r] = s_n[4 * g + r]; lreg[r] = s_len[4 * g + r]; dreg[r] = s_dst[4 * g + r];
   }
+  // positions past a sequence's length read as zero (pad_packed_sequence): written here instead of a memset of the whole
+  // tensor before the launch (dst_row is a permutation, so every output row belongs to exactly one sequence)
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (nreg[r] >= 0)
+      for (int t = lreg[r]; t < p.L; ++t) p.out[((long)dreg[r] * p.L + t) * 128 + dir * H + hid] = 0.f;
   auto load_gx = [&](int t, float (&dst)[3][4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -442,6 +448,14 @@ __global__ __launch_bounds__(256) void gru_bwd16_kernel(GruBwdParams p) {
     dh[r] = 0.f;
     nreg[r] = s_n[4 * g + r]; lreg[r] = s_len[4 * g + r]; dreg[r] = s_dst[4 * g + r];
   }
+  // no gradient reaches the input projections of padded positions: zeros, written here instead of a memset before the launch
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (nreg[r] >= 0)
+      for (int t = lreg[r]; t < p.L; ++t) {
+        float* gp = p.dgx + ((long)nreg[r] * p.L + t) * 384 + dir * G3 + hid;
+        gp[0] = 0.f; gp[H] = 0.f; gp[2 * H] = 0.f;
+      }
   // dW_hh[j][hid'] += sum_seq dgh[seq][j] h_prev[seq][hid'], computed transposed: rows hid' (tile ht), columns this
   // wave's j = q*64 + hid; k-step kk of group g is sequence 4g + kk = the row this lane computed itself (register kk)
   f32x4 accw[3][4];
@@ -597,7 +611,7 @@ int umpr_gru_recurrent_fwd(const float* gx, const float* whh_f, const float* bhh
   GruFwdParams p;
   p.gx = gx; p.whh[0] = whh_f; p.whh[1] = whh_r; p.bhh[0] = bhh_f; p.bhh[1] = bhh_r;
   p.lengths = lengths; p.order = order; p.dst_row = dst_row; p.out = out; p.saved = saved; p.N = N; p.L = L;
-  if (hipMemsetAsync(out, 0, (size_t)N * L * 128 * sizeof(float), s) != hipSuccess) {
+  if (g_gru_v1 && hipMemsetAsync(out, 0, (size_t)N * L * 128 * sizeof(float), s) != hipSuccess) {   // gru_fwd16 zeroes the tails itself
     umpr_set_error("gru_fwd: memset failed");
     return -2;
   }
@@ -620,7 +634,7 @@ int umpr_gru_bptt(const float* dout, const float* out, const float* saved, const
   p.dout = dout; p.out = out; p.saved = saved; p.whh[0] = whh_f; p.whh[1] = whh_r;
   p.lengths = lengths; p.order = order; p.dst_row = dst_row; p.dgx = dgx; p.dwhh_slab = dwhh_slab;
   p.dbias_slab = dbias_slab; p.N = N; p.L = L;
-  if (hipMemsetAsync(dgx, 0, (size_t)N * L * 384 * sizeof(float), s) != hipSuccess) {
+  if (g_gru_v1 && hipMemsetAsync(dgx, 0, (size_t)N * L * 384 * sizeof(float), s) != hipSuccess) {   // gru_bwd16 zeroes the tails itself
     umpr_set_error("gru_bwd: memset failed");
     return -2;
   }

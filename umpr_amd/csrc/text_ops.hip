@@ -680,6 +680,121 @@ inline int nblocks(long n, int cap = 4096) {
   return (int)b;
 }
 
+// ------------------------------------------------------------------------------------------------ review merge
+// src/model.py:150-151, 158: tanh(linear_u(repr_u) + linear_i(repr_i)); repr [B][256], W [128][256], out [B][128].  Batch-sized
+// and latency-bound: the two register-streaming fc launches per direction each walked their whole reduction in ONE workgroup
+// (15-17 us per launch at B = 32, eight launches forward + backward); these three kernels spread the same sums over 32-64
+// workgroups with every load of a thread independent of the one before.
+constexpr int MD = 128, MK = 256;
+
+// grid (MD / 4, cdiv(B, 32)); thread: row m = tid >> 3, eighth ks = tid & 7 of both reductions, four output columns
+__global__ __launch_bounds__(256) void merge_fwd_kernel(const float* __restrict__ ru, const float* __restrict__ ri,
+                                                        const float* __restrict__ Wu, const float* __restrict__ Wi, int B,
+                                                        float* __restrict__ out, float* __restrict__ out2) {
+  const int tid = threadIdx.x, ks = tid & 7, m = blockIdx.y * 32 + (tid >> 3), n0 = blockIdx.x * 4;
+  const int mc = m < B ? m : B - 1;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float4* xr = reinterpret_cast<const float4*>((q ? ri : ru) + (long)mc * MK);
+    const float4* wr = reinterpret_cast<const float4*>((q ? Wi : Wu) + (long)n0 * MK);
+    float4 x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = xr[j * 8 + ks];      // the 8 lanes of a row read 128 contiguous bytes per j
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 w = wr[c * (MK / 4) + j * 8 + ks];
+        acc[c] += x[j].x * w.x + x[j].y * w.y + x[j].z * w.z + x[j].w * w.w;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    acc[c] += __shfl_xor(acc[c], 1); acc[c] += __shfl_xor(acc[c], 2); acc[c] += __shfl_xor(acc[c], 4);
+  }
+  if (ks == 0 && m < B) {
+    float4 v = make_float4(tanhf(acc[0]), tanhf(acc[1]), tanhf(acc[2]), tanhf(acc[3]));
+    *reinterpret_cast<float4*>(out + (long)m * MD + n0) = v;
+    if (out2) *reinterpret_cast<float4*>(out2 + (long)m * MD + n0) = v;
+  }
+}
+
+// d_repr_s[m][k] = sum_n dpre[m][n] W_s[n][k],  dpre = d_out (1 - out^2).  grid (cdiv(B, 4), 2 sides); thread: float4 column
+// k4 = tid & 63, reduction quarter nq = tid >> 6 (32 n), four rows m; the quarters meet in LDS.
+__global__ __launch_bounds__(256) void merge_bwd_dx_kernel(const float* __restrict__ out, const float* __restrict__ d_out,
+                                                           const float* __restrict__ Wu, const float* __restrict__ Wi, int B,
+                                                           float* __restrict__ dru, float* __restrict__ dri) {
+  __shared__ float dp[4][MD];
+  __shared__ float4 part[3][4][64];
+  const int tid = threadIdx.x, k4 = tid & 63, nq = tid >> 6, m0 = blockIdx.x * 4;
+  const float* W = blockIdx.y ? Wi : Wu;
+  float* dr = blockIdx.y ? dri : dru;
+  for (int e = tid; e < 4 * MD; e += 256) {
+    const int m = m0 + e / MD, n = e % MD;
+    float v = 0.f;
+    if (m < B) { const float y = out[(long)m * MD + n]; v = d_out[(long)m * MD + n] * (1.f - y * y); }
+    dp[e / MD][n] = v;
+  }
+  __syncthreads();
+  float4 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* wp = reinterpret_cast<const float4*>(W + (long)(nq * 32) * MK) + k4;
+#pragma unroll 8
+  for (int i = 0; i < 32; ++i) {
+    const float4 w = wp[(long)i * (MK / 4)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = dp[r][nq * 32 + i];
+      acc[r].x += d * w.x; acc[r].y += d * w.y; acc[r].z += d * w.z; acc[r].w += d * w.w;
+    }
+  }
+  if (nq > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[nq - 1][r][k4] = acc[r];
+  }
+  __syncthreads();
+  if (nq == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float4 v = acc[r];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { const float4 o = part[q][r][k4]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      if (m0 + r < B) reinterpret_cast<float4*>(dr + (long)(m0 + r) * MK)[k4] = v;
+    }
+  }
+}
+
+// dW_s[n][k] = sum_m dpre[m][n] repr_s[m][k].  grid (MD / 4, 2 sides); thread: float4 column k4 = tid & 63 of row n0 + (tid >> 6)
+__global__ __launch_bounds__(256) void merge_bwd_dw_kernel(const float* __restrict__ out, const float* __restrict__ d_out,
+                                                           const float* __restrict__ ru, const float* __restrict__ ri, int B,
+                                                           float* __restrict__ dWu, float* __restrict__ dWi) {
+  __shared__ float dp[128][4];
+  const int tid = threadIdx.x, k4 = tid & 63, nn = tid >> 6, n0 = blockIdx.x * 4;
+  const float* R = blockIdx.y ? ri : ru;
+  float* dW = blockIdx.y ? dWi : dWu;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int mb = 0; mb < B; mb += 128) {          // B <= 128 in practice: one pass
+    const int mcnt = min(128, B - mb);
+    __syncthreads();
+    for (int e = tid; e < mcnt * 4; e += 256) {
+      const int m = mb + (e >> 2), n = n0 + (e & 3);
+      const float y = out[(long)m * MD + n];
+      dp[e >> 2][e & 3] = d_out[(long)m * MD + n] * (1.f - y * y);
+    }
+    __syncthreads();
+    const float4* rp = reinterpret_cast<const float4*>(R + (long)mb * MK) + k4;
+#pragma unroll 8
+    for (int m = 0; m < mcnt; ++m) {
+      const float4 x = rp[(long)m * (MK / 4)];
+      const float d = dp[m][nn];
+      acc.x += d * x.x; acc.y += d * x.y; acc.z += d * x.z; acc.w += d * x.w;
+    }
+  }
+  reinterpret_cast<float4*>(dW + (long)(n0 + nn) * MK)[k4] = acc;
+}
+
 }  // namespace
 
 // ---- internal host wrappers --------------------------------------------------------------------------------
@@ -753,6 +868,20 @@ int umpr_copy_or_add(const float* src, float* dst, long n, int accumulate, hipSt
 int umpr_fill(float* p, long n, float v, hipStream_t s) {
   fill_kernel<<<nblocks(n), 256, 0, s>>>(p, n, v);
   UMPR_LAUNCH_CHECK("fill");
+  return 0;
+}
+int umpr_review_merge_fwd_impl(const float* ru, const float* ri, const float* Wu, const float* Wi, int B, float* out, float* out2,
+                               hipStream_t s) {
+  merge_fwd_kernel<<<dim3(MD / 4, cdiv(B, 32)), 256, 0, s>>>(ru, ri, Wu, Wi, B, out, out2);
+  UMPR_LAUNCH_CHECK("merge_fwd");
+  return 0;
+}
+int umpr_review_merge_bwd_impl(const float* ru, const float* ri, const float* Wu, const float* Wi, const float* out,
+                               const float* d_out, int B, float* dru, float* dri, float* dWu, float* dWi, hipStream_t s) {
+  merge_bwd_dx_kernel<<<dim3(cdiv(B, 4), 2), 256, 0, s>>>(out, d_out, Wu, Wi, B, dru, dri);
+  UMPR_LAUNCH_CHECK("merge_bwd_dx");
+  merge_bwd_dw_kernel<<<dim3(MD / 4, 2), 256, 0, s>>>(out, d_out, ru, ri, B, dWu, dWi);
+  UMPR_LAUNCH_CHECK("merge_bwd_dw");
   return 0;
 }
 int umpr_tanh_bwd(const float* y, const float* gy, float* gx, long n, hipStream_t s) {

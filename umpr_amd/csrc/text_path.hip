@@ -139,6 +139,9 @@ int umpr_review_net_fwd(const int64_t* ids_pair, const float* emb, int E, const 
                                                                          A.argrow, ws, ws_bytes, stream)) return rc;
   if (int rc = umpr_snet_fwd(gru_u, P[9], P[10], A.soft_u, L, B, S, L, A.su.U, A.su.P, A.su.wsum, A.su.sa, A.repr_u + D, 2 * D, stream)) return rc;
   if (int rc = umpr_snet_fwd(gru_i, P[11], P[12], A.soft_i, L, B, S, L, A.si.U, A.si.P, A.si.wsum, A.si.sa, A.repr_i + D, 2 * D, stream)) return rc;
+  static const bool merge_small = umpr_env_on("UMPR_MERGE_SMALL");
+  if (B <= 256 && merge_small)   // one kernel writes the caller's tensor and the arena's copy for backward
+    return umpr_review_merge_fwd_impl(A.repr_u, A.repr_i, P[13], P[14], B, out, A.merged, static_cast<hipStream_t>(stream));
   if (int rc = umpr_review_merge_fwd(A.repr_u, A.repr_i, P[13], P[14], B, A.merged, stream)) return rc;
   if (hipMemcpyAsync(out, A.merged, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)) != hipSuccess) {
     umpr_set_error("review_net_fwd: copy failed");

@@ -149,6 +149,12 @@ int umpr_coattn_bwd_impl(const float* Gu, const float* Gi, const float* M, const
 
 // text_ops.hip
 int umpr_tanh_bwd(const float* y, const float* gy, float* gx, long n, hipStream_t s);
+// tanh(repr_u W_u^T + repr_i W_i^T) (model.py:150-158) and its backward: repr [B][256], W [128][256], out [B][128]; out2 (optional)
+// receives a second copy of out
+int umpr_review_merge_fwd_impl(const float* ru, const float* ri, const float* Wu, const float* Wi, int B, float* out, float* out2,
+                               hipStream_t s);
+int umpr_review_merge_bwd_impl(const float* ru, const float* ri, const float* Wu, const float* Wi, const float* out,
+                               const float* d_out, int B, float* dru, float* dri, float* dWu, float* dWi, hipStream_t s);
 int umpr_relu_bwd(const float* y, const float* gy, float* gx, long n, hipStream_t s);
 size_t umpr_colsum_ws_bytes(long rows, int cols);
 int umpr_colsum(const float* src, long rows, int cols, long ld, float* dst, int accumulate, float* ws, size_t ws_bytes,

@@ -1040,8 +1040,13 @@ class UMPR(nn.Module):
                 idx, lens, order, lens_ui, ord_ui = self._static_index
             else:
                 idx, lens, order, lens_ui, ord_ui = self._index_upload(u_lengths, i_lengths, ui_lengths if full else None, device)
-            ids_pair = torch.empty(2 * N, L, device=device, dtype=torch.int64)
-            lib().call("umpr_concat_ids", user_reviews, item_reviews, N * L, ids_pair, stream_ptr())
+            if (item_reviews.data_ptr() == user_reviews.data_ptr() + N * L * 8
+                    and item_reviews.untyped_storage().data_ptr() == user_reviews.untyped_storage().data_ptr()):
+                # the caller keeps the two back to back in one allocation (umpr_amd/graphs.py): that IS the [2N][L] tensor
+                ids_pair = user_reviews.as_strided((2 * N, L), (L, 1))
+            else:
+                ids_pair = torch.empty(2 * N, L, device=device, dtype=torch.int64)
+                lib().call("umpr_concat_ids", user_reviews, item_reviews, N * L, ids_pair, stream_ptr())
             rr = _ReviewNetF.apply(ids_pair, lens, order, emb, (B, S, L), b16_gemm, b16_scores, *self._review_params(device))
             if full:
                 cu, ci, pp, pn = _ControlNetF.apply(ui_reviews.view(B * S_ui, L_ui), ids_pair, lens_ui, ord_ui, lens, order, emb,

@@ -145,27 +145,38 @@ class FusedAdam:
         self._early = self._early_done = None
 
     # ---- hipGraph support: the Adam kernel's per-step scalars live in device memory (umpr_adam_step_dev) --------------------
-    def enable_graph_mode(self):
+    def enable_graph_mode(self, hyper=None):
         """From now on step() launches the device-scalar form of the kernel; prepare_step() must run before every step (eager or
-        replayed) to refresh the scalars for the step about to be taken.  The update is bit-identical to the plain form."""
+        replayed) to refresh the scalars for the step about to be taken.  The update is bit-identical to the plain form.
+        `hyper`: a device float32 [groups][4] view the CALLER keeps fresh from hyper_rows() (umpr_amd/graphs.py carries the scalars
+        inside its one upload per step); prepare_step() is then not used."""
         dev = self.groups[0].p.device
+        if hyper is not None:
+            assert hyper.shape == (len(self.groups), 4) and hyper.dtype == torch.float32 and hyper.device == dev
+            self._hyper = hyper
+            self._hyper_host = None
+            return
         self._hyper = torch.zeros(len(self.groups), 4, device=dev, dtype=torch.float32)
         self._hyper_host = [torch.zeros(len(self.groups), 4, dtype=torch.float32).pin_memory() for _ in range(8)]
         self._hyper_ev = [None] * 8
         self._hyper_k = 0
 
-    def prepare_step(self, grad_scale=1.0):
+    def hyper_rows(self, grad_scale=1.0):
+        """[grad_scale, lr / (1 - b1^t), 1 / sqrt(1 - b2^t), weight_decay] per group for the step about to be taken (float64 on
+        the host, as the plain kernel's launcher computes them)."""
         t = self.step_count + 1
+        return [[float(grad_scale), float(self.lr / (1.0 - self.betas[0] ** t)), float(1.0 / (1.0 - self.betas[1] ** t) ** 0.5),
+                 float(g.weight_decay)] for g in self.groups]
+
+    def prepare_step(self, grad_scale=1.0):
+        rows = self.hyper_rows(grad_scale)
+        assert self._hyper_host is not None, "prepare_step: this optimiser's scalars live in a caller-owned buffer (hyper_rows())"
         k = self._hyper_k % 8
         self._hyper_k += 1
         if self._hyper_ev[k] is not None:
             self._hyper_ev[k].synchronize()
         h = self._hyper_host[k]
-        for gi, g in enumerate(self.groups):
-            h[gi, 0] = float(grad_scale)
-            h[gi, 1] = float(self.lr / (1.0 - self.betas[0] ** t))
-            h[gi, 2] = float(1.0 / (1.0 - self.betas[1] ** t) ** 0.5)
-            h[gi, 3] = float(g.weight_decay)
+        h.copy_(torch.tensor(rows, dtype=torch.float32))
         self._hyper.copy_(h, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self._hyper.device))
