@@ -62,7 +62,8 @@ long umpr_debug_wino_fix_count(void);
  * ids [N*L] int64; emb [vocab][E]; GRU weights in nn.GRU layout (gate order r,z,n): w_ih [192][E], w_hh [192][64],
  * b_ih/b_hh [192], forward direction then "_reverse".  lengths [N]; order [N] = sorted_indices (descending length,
  * the tie order torch.sort produced); dst_row [N]: input row n lands in output row dst_row[n] (= sorted_indices[n]
- * for the reference's semantics).  out [N][L][128] (zeros past each length).  saved [2][N][L][4][64] (gates for
+ * for the reference's semantics; must be a permutation of 0..N-1: each output row is written - values up to its length, zeros
+ * past it - by the sequence that owns it).  out [N][L][128] (zeros past each length).  saved [2][N][L][4][64] (gates for
  * backward) or NULL for inference. */
 size_t umpr_embed_gru_bidir_ws_bytes(int N, int L, int E);
 int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of umpr_gemm_f32 at the text path's shapes, fp32 and bf16-operand mode (HIP events).
-usage: python tools/bench_gemm.py"""
+usage: python tools/bench_gemm.py [M,N,K,ta,tb,splitk ...]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,9 @@ SHAPES = [  # (M, N, K, ta, tb, splitk)
 
 
 def main():
+    global SHAPES
+    if len(sys.argv) > 1:      # M,N,K,ta,tb,splitk ...
+        SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
     L = lib()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream

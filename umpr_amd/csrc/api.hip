@@ -130,35 +130,62 @@ long umpr_debug_wino_fix_count(void) { return umpr_wino_last_fix_count(); }
 size_t umpr_embed_gru_bidir_ws_bytes(int N, int L, int E) {
   const size_t tiles = umpr_gru_tiles(N);
   // gx / dgx [N*L*384] + dWhh slabs + bias slabs + split-K slab for dW_ih (forward: the stacked input weights) + the
-  // stacked [384][E] weight gradient + the gathered embedding rows [N*L][E]
-  return ((size_t)N * L * 384 + tiles * 2 * G3 * H + tiles * 2 * 2 * G3 + (size_t)128 * G3 * E + (size_t)2 * G3 * E +
-          (size_t)N * L * E) * sizeof(float);
+  // stacked [384][Ep] weight gradient + the gathered embedding rows [N*L][Ep]; Ep = E rounded up to 4 floats (16-B rows)
+  const size_t Ep = (size_t)((E + 3) & ~3);
+  return ((size_t)N * L * 384 + tiles * 2 * G3 * H + tiles * 2 * 2 * G3 + (size_t)128 * G3 * Ep + (size_t)2 * G3 * Ep +
+          (size_t)N * L * Ep) * sizeof(float);
 }
 namespace {
 // The token rows of the embedding table, gathered ONCE into a contiguous [N*L][E] matrix (one wave per row, whole 1200-B rows)
 // instead of inside the projection GEMM, whose 128 x 128 tiles fetched 64-B pieces of random rows of the 480 MB table stage
 // by stage and three times over (one per column tile): 228 us for 260 MB at E = 300.  UMPR_EMB_GATHER=0: gather in the GEMM.
 const bool g_emb_gather = umpr_env_on("UMPR_EMB_GATHER");
+// Rows are written with a pitch of Ep = E rounded up to 4 floats, the tail zero-filled: the projection GEMMs then stage both
+// operands as float4 (GloVe-50d: 200-B rows made every load of them a scalar one - 63 us for the [25600 x 50] x [50 x 384]
+// product at batch 32, against the 39 MB it writes).  Zero columns add exact zeros to the sums.
 __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
-                                                          int E, float* __restrict__ out, long rows) {
+                                                          int E, int Ep, float* __restrict__ out, long rows) {
   const int lane = threadIdx.x & 63;
   for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
     const float* src = emb + ids[r] * (long)E;
-    float* dst = out + r * (long)E;
+    float* dst = out + r * (long)Ep;
     if ((E & 3) == 0) {
       for (int c = lane; c < E / 4; c += 64) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(src)[c];
     } else {
-      for (int c = lane; c < E; c += 64) dst[c] = src[c];
+      for (int c = lane; c < Ep; c += 64) dst[c] = c < E ? src[c] : 0.f;
     }
   }
 }
-float* gathered_rows(float* ws, int N, int L, int E) {
-  return ws + (size_t)N * L * 384 + (size_t)umpr_gru_tiles(N) * (2 * G3 * H + 2 * 2 * G3) + (size_t)128 * G3 * E + (size_t)2 * G3 * E;
+// [W_ih_f ; W_ih_r] as one [384][Ep] matrix (zero tail columns) + [b_ih_f ; b_ih_r]
+__global__ __launch_bounds__(256) void stack_wih_kernel(const float* __restrict__ wf, const float* __restrict__ wr,
+                                                        const float* __restrict__ bf, const float* __restrict__ br, int E, int Ep,
+                                                        float* __restrict__ wst, float* __restrict__ bst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 2 * G3 * Ep) {
+    const int row = i / Ep, c = i - row * Ep;
+    const float* src = row < G3 ? wf + (long)row * E : wr + (long)(row - G3) * E;
+    wst[i] = c < E ? src[c] : 0.f;
+  }
+  if (i < 2 * G3) bst[i] = i < G3 ? bf[i] : br[i - G3];
 }
-int gather_rows(const int64_t* ids, const float* emb, int E, float* out, long rows, hipStream_t s) {
+// rows 0..191 / 192..383 of the stacked [384][Ep] weight gradient to (or onto) the two parameters' [192][E] gradients
+__global__ __launch_bounds__(256) void unstack_dwih_kernel(const float* __restrict__ stacked, int E, int Ep, float* __restrict__ df,
+                                                           float* __restrict__ dr, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * G3 * E) return;
+  const int row = i / E, c = i - row * E;
+  const float v = stacked[(long)row * Ep + c];
+  float* dst = row < G3 ? df + (long)row * E + c : dr + (long)(row - G3) * E + c;
+  *dst = accumulate ? *dst + v : v;
+}
+inline int emb_pitch(int E) { return g_emb_gather ? (E + 3) & ~3 : E; }
+float* gathered_rows(float* ws, int N, int L, int Ep) {
+  return ws + (size_t)N * L * 384 + (size_t)umpr_gru_tiles(N) * (2 * G3 * H + 2 * 2 * G3) + (size_t)128 * G3 * Ep + (size_t)2 * G3 * Ep;
+}
+int gather_rows(const int64_t* ids, const float* emb, int E, int Ep, float* out, long rows, hipStream_t s) {
   long blocks = (rows + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  gather_rows_kernel<<<(unsigned)blocks, 256, 0, s>>>(ids, emb, E, out, rows);
+  gather_rows_kernel<<<(unsigned)blocks, 256, 0, s>>>(ids, emb, E, Ep, out, rows);
   UMPR_LAUNCH_CHECK("gather_rows");
   return 0;
 }
@@ -176,25 +203,23 @@ int umpr_embed_gru_bidir_fwd(const int64_t* ids, const float* emb, int E,
   // embedding rows are fetched once instead of twice, and N = 384 fills three 128-column tiles where 192 wasted half of
   // its second one).  The stacked [384][E] weight / [384] bias live behind gx in the workspace.
   if (ws_bytes >= umpr_embed_gru_bidir_ws_bytes(N, L, E)) {
+    const int Ep = emb_pitch(E);
     float* wst = gx + (size_t)N * L * 384 + (size_t)umpr_gru_tiles(N) * (2 * G3 * H + 2 * 2 * G3);   // the dW_ih slab area
-    float* bst = wst + (size_t)2 * G3 * E;
+    float* bst = wst + (size_t)2 * G3 * Ep;
     const hipStream_t s = S(stream);
-    {  // stack the two directions' input weights and biases: one launch
-      const float* src[4] = {w_ih_f, w_ih_r, b_ih_f, b_ih_r};
-      float* dst[4] = {wst, wst + (size_t)G3 * E, bst, bst + G3};
-      const long cnt[4] = {(long)G3 * E, (long)G3 * E, G3, G3};
-      if (int rc = umpr_multi_copy(src, dst, cnt, nullptr, 4, s)) return rc;
-    }
+    // stack the two directions' input weights and biases: one launch
+    stack_wih_kernel<<<cdiv(2 * G3 * Ep, 256), 256, 0, s>>>(w_ih_f, w_ih_r, b_ih_f, b_ih_r, E, Ep, wst, bst);
+    UMPR_LAUNCH_CHECK("stack_wih");
     UmprGemm g;
     if (g_emb_gather) {
-      float* xg = gathered_rows(ws, N, L, E);
-      if (int rc = gather_rows(ids, emb, E, xg, (long)N * L, s)) return rc;
-      g.A = xg; g.lda = E;
+      float* xg = gathered_rows(ws, N, L, Ep);
+      if (int rc = gather_rows(ids, emb, E, Ep, xg, (long)N * L, s)) return rc;
+      g.A = xg; g.lda = Ep;
     } else {
       g.A = emb; g.lda = E; g.gatherA = ids;
     }
-    g.B = wst; g.ldb = E; g.transB = true;
-    g.C = gx; g.ldc = 384; g.M = N * L; g.N = 2 * G3; g.K = E; g.bias = bst; g.bias_mode = 1;
+    g.B = wst; g.ldb = Ep; g.transB = true;
+    g.C = gx; g.ldc = 384; g.M = N * L; g.N = 2 * G3; g.K = Ep; g.bias = bst; g.bias_mode = 1;
     if (int rc = umpr_gemm(g, s)) return rc;
   } else {
     for (int d = 0; d < 2; ++d) {  // small workspace (inference callers sized for gx only): one GEMM per direction
@@ -239,23 +264,22 @@ int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E, co
   }
   {  // [dW_ih_f ; dW_ih_r] [384][E] = dgx^T emb[ids]: one split-K gather-GEMM for both directions, then rows 0..191 /
      // 192..383 are copied (or added) to their parameters' gradients
-    float* stacked = kslab + (size_t)128 * G3 * E;
+    const int Ep = emb_pitch(E);
+    float* stacked = kslab + (size_t)128 * G3 * Ep;
     UmprGemm g;
     g.A = dgx; g.lda = 384; g.transA = true;
     if (g_emb_gather) {
-      float* xg = gathered_rows(ws, N, L, E);
-      if (int rc = gather_rows(ids, emb, E, xg, (long)N * L, S(stream))) return rc;
-      g.B = xg; g.ldb = E;
+      float* xg = gathered_rows(ws, N, L, Ep);
+      if (int rc = gather_rows(ids, emb, E, Ep, xg, (long)N * L, S(stream))) return rc;
+      g.B = xg; g.ldb = Ep;
     } else {
       g.B = emb; g.ldb = E; g.gatherB = ids;
     }
-    g.C = stacked; g.ldc = E; g.M = 2 * G3; g.N = E; g.K = N * L; g.split_k = 0; g.ws = kslab;
-    g.ws_bytes = (size_t)128 * G3 * E * sizeof(float);
+    g.C = stacked; g.ldc = Ep; g.M = 2 * G3; g.N = Ep; g.K = N * L; g.split_k = 0; g.ws = kslab;   // (tail columns: zeros)
+    g.ws_bytes = (size_t)128 * G3 * Ep * sizeof(float);
     if (int rc = umpr_gemm(g, S(stream))) return rc;
-    const float* csrc[2] = {stacked, stacked + (size_t)G3 * E};
-    const long ccnt[2] = {(long)G3 * E, (long)G3 * E};
-    const int cacc[2] = {accumulate, accumulate};
-    if (int rc = umpr_multi_copy(csrc, dwih, ccnt, cacc, 2, S(stream))) return rc;
+    unstack_dwih_kernel<<<cdiv(2 * G3 * E, 256), 256, 0, S(stream)>>>(stacked, E, Ep, dwih[0], dwih[1], accumulate);
+    UMPR_LAUNCH_CHECK("unstack_dwih");
   }
   return 0;
 }

@@ -312,62 +312,56 @@ struct FinishParams {
   int SL;
 };
 
-// 1024 threads per sample: the weighted sums over the SL positions run as 8 chains of SL/8 terms per column
+// 1024 threads per (sample, side): the weighted sums over the SL positions run as 8 chains of SL/8 terms per column.  Side 0 =
+// the user's columns (colmax -> soft_u -> atte_u), side 1 = the item's rows; one workgroup each (grid (B, 2)): at batch 32 a grid
+// of B workgroups doing both sides one after the other left 7/8 of the chip idle for 33 us.
 __global__ __launch_bounds__(1024) void coattn_finish_kernel(FinishParams p) {
-  extern __shared__ float sm[];  // su[SL], si[SL]
+  extern __shared__ float sm[];  // s[SL]
   __shared__ float red[16];
   __shared__ float part[8][D];
-  const int tid = threadIdx.x, b = blockIdx.x, SL = p.SL;
-  float* su = sm; float* si = sm + SL;
-  float mu = -INFINITY, mi = -INFINITY;
+  const int tid = threadIdx.x, b = blockIdx.x, side = blockIdx.y, SL = p.SL;
+  const float* max_part = side ? p.rowmax_part : p.colmax_part;
+  const int* arg_part = side ? p.argrow_part : p.argcol_part;
+  const int nparts = side ? p.ksplit : p.nblk;     // (row parts: ascending column ranges, ties keep the first column)
+  float* vmax = side ? p.rowmax : p.colmax;
+  int* varg = side ? p.argrow : p.argcol;
+  float* soft = side ? p.soft_i : p.soft_u;
+  float* sv = sm;
+  float mx = -INFINITY;
   for (int k = tid; k < SL; k += 1024) {
     float v = -INFINITY; int idx = 0x7fffffff;
-    for (int q = 0; q < p.nblk; ++q) {
-      const long o = ((long)b * p.nblk + q) * SL + k;
-      better_first(v, idx, p.colmax_part[o], p.argcol_part[o]);
+    for (int q = 0; q < nparts; ++q) {
+      const long o = ((long)b * nparts + q) * SL + k;
+      better_first(v, idx, max_part[o], arg_part[o]);
     }
-    p.colmax[(long)b * SL + k] = v; p.argcol[(long)b * SL + k] = idx;
-    su[k] = v; mu = fmaxf(mu, v);
-    float rv = -INFINITY; int ridx = 0x7fffffff;
-    for (int q = 0; q < p.ksplit; ++q) {   // ascending column ranges: ties keep the first column
-      const long o = ((long)b * p.ksplit + q) * SL + k;
-      better_first(rv, ridx, p.rowmax_part[o], p.argrow_part[o]);
-    }
-    p.rowmax[(long)b * SL + k] = rv; p.argrow[(long)b * SL + k] = ridx;
-    si[k] = rv; mi = fmaxf(mi, rv);
+    vmax[(long)b * SL + k] = v; varg[(long)b * SL + k] = idx;
+    sv[k] = v; mx = fmaxf(mx, v);
   }
-  mu = block_max(mu, red);
-  mi = block_max(mi, red);
-  float zu = 0.f, zi = 0.f;
+  mx = block_max(mx, red);
+  float z = 0.f;
   for (int k = tid; k < SL; k += 1024) {
-    const float eu = expf(su[k] - mu), ei = expf(si[k] - mi);
-    su[k] = eu; si[k] = ei; zu += eu; zi += ei;
+    const float e = expf(sv[k] - mx);
+    sv[k] = e; z += e;
   }
-  zu = block_sum(zu, red);
-  zi = block_sum(zi, red);
+  z = block_sum(z, red);
   for (int k = tid; k < SL; k += 1024) {
-    su[k] /= zu; si[k] /= zi;
-    p.soft_u[(long)b * SL + k] = su[k];
-    p.soft_i[(long)b * SL + k] = si[k];
+    sv[k] /= z;
+    soft[(long)b * SL + k] = sv[k];
   }
   __syncthreads();
   const int c = tid & 127, grp = tid >> 7;
-  for (int which = 0; which < 2; ++which) {
-    const float* G = (which == 0 ? p.Gu : p.Gi) + (long)b * SL * D;
-    const float* s = which == 0 ? su : si;
-    float a = 0.f;
-    for (int k = grp; k < SL; k += 8) a += s[k] * G[(long)k * D + c];
-    part[grp][c] = a;
-    __syncthreads();
-    if (grp == 0) {
-      const float v = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
-      if (which == 0) p.atte_u[(long)b * p.ld_u + c] = v; else p.atte_i[(long)b * p.ld_i + c] = v;
-    }
-    __syncthreads();
+  const float* G = (side ? p.Gi : p.Gu) + (long)b * SL * D;
+  float a = 0.f;
+#pragma unroll 4
+  for (int k = grp; k < SL; k += 8) a += sv[k] * G[(long)k * D + c];
+  part[grp][c] = a;
+  __syncthreads();
+  if (grp == 0) {
+    const float v = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+    if (side == 0) p.atte_u[(long)b * p.ld_u + c] = v; else p.atte_i[(long)b * p.ld_i + c] = v;
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
 struct BwdPrepParams {
   const float* Gu; const float* Gi;
   const float* d_atte_u; long ld_du; const float* d_atte_i; long ld_di;   // [B][128] (strided rows)
@@ -377,37 +371,39 @@ struct BwdPrepParams {
   int SL;
 };
 
+// grid (B, 2): one workgroup per (sample, side), as coattn_finish_kernel
 __global__ __launch_bounds__(1024) void coattn_bwd_prep_kernel(BwdPrepParams p) {
-  extern __shared__ float sm[];  // ds_u[SL], ds_i[SL]
+  extern __shared__ float sm[];  // ds[SL]
   __shared__ float red[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, SL = p.SL;
-  float* dsu = sm; float* dsi = sm + SL;
-  const float dau0 = p.d_atte_u[(long)b * p.ld_du + lane], dau1 = p.d_atte_u[(long)b * p.ld_du + 64 + lane];
-  const float dai0 = p.d_atte_i[(long)b * p.ld_di + lane], dai1 = p.d_atte_i[(long)b * p.ld_di + 64 + lane];
-  for (int k = wave; k < SL; k += 16) {
-    const float* gu = p.Gu + ((long)b * SL + k) * D;
-    const float* gi = p.Gi + ((long)b * SL + k) * D;
-    float su = gu[lane] * dau0 + gu[64 + lane] * dau1;
-    float si = gi[lane] * dai0 + gi[64 + lane] * dai1;
-    su = wave_sum(su); si = wave_sum(si);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, side = blockIdx.y, SL = p.SL;
+  float* ds = sm;
+  const float* Gs = (side ? p.Gi : p.Gu) + (long)b * SL * D;
+  const float* d_atte = side ? p.d_atte_i + (long)b * p.ld_di : p.d_atte_u + (long)b * p.ld_du;
+  const float* d_soft = side ? p.d_soft_i : p.d_soft_u;
+  const float* soft = (side ? p.soft_i : p.soft_u) + (long)b * SL;
+  const float* vmax = (side ? p.rowmax : p.colmax) + (long)b * SL;
+  float* dS = (side ? p.dSr : p.dSc) + (long)b * SL;
+  const float da0 = d_atte[lane], da1 = d_atte[64 + lane];
+  for (int k = wave; k < SL; k += 32) {        // two positions per trip: both rows' loads in flight before either reduction
+    const int k2 = k + 16;
+    const bool has2 = k2 < SL;
+    const float* g = Gs + (long)k * D;
+    const float* g2 = Gs + (long)(has2 ? k2 : k) * D;
+    const float a0 = g[lane], a1 = g[64 + lane], b0 = g2[lane], b1 = g2[64 + lane];
+    const float v = wave_sum(a0 * da0 + a1 * da1);
+    const float v2 = wave_sum(b0 * da0 + b1 * da1);
     if (lane == 0) {
-      dsu[k] = su + (p.d_soft_u ? p.d_soft_u[(long)b * SL + k] : 0.f);
-      dsi[k] = si + (p.d_soft_i ? p.d_soft_i[(long)b * SL + k] : 0.f);
+      ds[k] = v + (d_soft ? d_soft[(long)b * SL + k] : 0.f);
+      if (has2) ds[k2] = v2 + (d_soft ? d_soft[(long)b * SL + k2] : 0.f);
     }
   }
   __syncthreads();
-  float du = 0.f, di = 0.f;
+  float dsum = 0.f;
+  for (int k = tid; k < SL; k += 1024) dsum += soft[k] * ds[k];
+  dsum = block_sum(dsum, red);
   for (int k = tid; k < SL; k += 1024) {
-    du += p.soft_u[(long)b * SL + k] * dsu[k];
-    di += p.soft_i[(long)b * SL + k] * dsi[k];
-  }
-  du = block_sum(du, red);
-  di = block_sum(di, red);
-  for (int k = tid; k < SL; k += 1024) {
-    const long o = (long)b * SL + k;
-    const float cm = p.colmax[o], rm = p.rowmax[o];
-    p.dSc[o] = p.soft_u[o] * (dsu[k] - du) * (1.f - cm * cm);
-    p.dSr[o] = p.soft_i[o] * (dsi[k] - di) * (1.f - rm * rm);
+    const float m = vmax[k];
+    dS[k] = soft[k] * (ds[k] - dsum) * (1.f - m * m);
   }
 }
 
@@ -517,7 +513,7 @@ int umpr_coattn_fwd_impl(const float* Gu, const float* Gi, const float* M, int B
   else coattn_scores_kernel<<<dim3(nblk, B, ksplit), 256, 0, s>>>(sp);
   UMPR_LAUNCH_CHECK("coattn_scores");
   FinishParams fp{Gu, Gi, cpart, apart, nblk, rpart, arpart, ksplit, rowmax, argrow, colmax, argcol, soft_u, soft_i, atte_u, ld_u, atte_i, ld_i, SL};
-  coattn_finish_kernel<<<B, 1024, 2 * SL * sizeof(float), s>>>(fp);
+  coattn_finish_kernel<<<dim3(B, 2), 1024, SL * sizeof(float), s>>>(fp);
   UMPR_LAUNCH_CHECK("coattn_finish");
   return 0;
 }
@@ -536,7 +532,7 @@ int umpr_coattn_bwd_impl(const float* Gu, const float* Gi, const float* M, const
   float* dSc = ws; float* dSr = ws + (size_t)B * SL; float* dT = dSr + (size_t)B * SL;
   float* slab = dT + (size_t)B * SL * D;
   BwdPrepParams pp{Gu, Gi, d_atte_u, ld_du, d_atte_i, ld_di, d_soft_u, d_soft_i, soft_u, soft_i, colmax, rowmax, dSc, dSr, SL};
-  coattn_bwd_prep_kernel<<<B, 1024, 2 * SL * sizeof(float), s>>>(pp);
+  coattn_bwd_prep_kernel<<<dim3(B, 2), 1024, SL * sizeof(float), s>>>(pp);
   UMPR_LAUNCH_CHECK("coattn_bwd_prep");
   BwdRowsParams rp{Gu, T, soft_u, soft_i, d_atte_u, ld_du, d_atte_i, ld_di, dSc, dSr, argcol, argrow, dGu, dT, dGi, SL, accumulate};
   coattn_bwd_rows_kernel<<<dim3(cdiv(SL, 16), B), 256, 4 * SL * sizeof(float), s>>>(rp);
