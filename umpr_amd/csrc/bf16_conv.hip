@@ -1064,6 +1064,67 @@ __global__ void maxpool2_bf16_fwd_kernel(const bf16_t* __restrict__ x, long xps,
 
 // gx = pool backward routed to the FIRST maximum of each window (order (0,0),(0,1),(1,0),(1,1), like the fp32 kernel),
 // zero where that maximum is not > 0 (ReLU of the activation that fed the pool); one thread per INPUT pixel, pads zero
+// Backward of the 2x2 max-pool with the ReLU mask of the layer before it, one thread per pooled pixel: the window's four
+// inputs are read ONCE (64 B), the pooled gradient once (16 B), and the four gradient pixels leave as two 32-B pieces.  (The
+// first version ran one thread per INPUT pixel: every thread of a window fetched the whole window again and redid its argmax -
+// 80 B through the texture path per 16 B written, 2.0 TB/s over the five pools of a batch-64 step.)  The guards of the gx
+// plane are covered by the same index space: a guard pixel of the POOLED map owns the guard pixels of the input map that sit
+// where its window would be (column 0 of its two rows; the zero row above an image; both for the corner), and the indices
+// past the pooled map zero the lead / tail of the plane.
+__global__ __launch_bounds__(256) void maxpool2_bf16_bwd_relu_win_kernel(const bf16_t* __restrict__ x, long xps,
+                                                                         const bf16_t* __restrict__ gy, long gps,
+                                                                         bf16_t* __restrict__ gx, long gxps, int H, int W,
+                                                                         unsigned ptot_out, long ptot_in, long lead) {
+  const unsigned Ho = H / 2, Wo = W / 2, RWo = Wo + 1, RWi = W + 1;
+  const int cb = blockIdx.y;
+  const unsigned extra = (unsigned)(gxps - ptot_in);        // lead + tail pixels of the plane
+  bf16x8 zero;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero[e] = (bf16_t)0.f;
+  bf16_t* gplane = gx + (long)cb * gxps * 8;                 // gx points at pixel 0; the plane starts `lead` pixels before it
+  for (unsigned P = blockIdx.x * blockDim.x + threadIdx.x; P < ptot_out + extra; P += gridDim.x * blockDim.x) {
+    if (P >= ptot_out) {                                     // plane guards: [-lead, 0) and [ptot_in, gxps - lead)
+      const long q = P - ptot_out;
+      const long pix = q < lead ? q - lead : ptot_in + (q - lead);
+      *reinterpret_cast<bf16x8*>(gplane + pix * 8) = zero;
+      continue;
+    }
+    const unsigned row = P / RWo, col = P - row * RWo;
+    const unsigned n = row / (Ho + 1), rr = row - n * (Ho + 1);
+    if (rr == 0) {                                           // the zero row above image n (or below the last image)
+      bf16_t* d = gplane + ((long)n * (H + 1) * RWi) * 8;
+      if (col == 0) *reinterpret_cast<bf16x8*>(d) = zero;
+      else { *reinterpret_cast<bf16x8*>(d + (2 * col - 1) * 8) = zero; *reinterpret_cast<bf16x8*>(d + (2 * col) * 8) = zero; }
+      continue;
+    }
+    const long r1 = (long)n * (H + 1) + 2 * (rr - 1) + 1;    // first of the window's two input rows
+    if (col == 0) {
+      *reinterpret_cast<bf16x8*>(gplane + (r1 * RWi) * 8) = zero;
+      *reinterpret_cast<bf16x8*>(gplane + ((r1 + 1) * RWi) * 8) = zero;
+      continue;
+    }
+    const long Pw = r1 * RWi + 2 * (col - 1) + 1;
+    const bf16_t* s = x + ((long)cb * xps + Pw) * 8;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(s), b = *reinterpret_cast<const bf16x8*>(s + 8);
+    const bf16x8 c = *reinterpret_cast<const bf16x8*>(s + (long)RWi * 8), d = *reinterpret_cast<const bf16x8*>(s + (long)RWi * 8 + 8);
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(gy + ((long)cb * gps + P) * 8);
+    bf16x8 o[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int arg = 0; float m = (float)a[e];                    // first maximum wins, as in the forward kernel and in ATen
+      if ((float)b[e] > m) { m = (float)b[e]; arg = 1; }
+      if ((float)c[e] > m) { m = (float)c[e]; arg = 2; }
+      if ((float)d[e] > m) { m = (float)d[e]; arg = 3; }
+      const bool live = m > 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q][e] = (live && arg == q) ? g[e] : (bf16_t)0.f;
+    }
+    bf16_t* dst = gplane + Pw * 8;
+    *reinterpret_cast<bf16x8*>(dst) = o[0]; *reinterpret_cast<bf16x8*>(dst + 8) = o[1];
+    *reinterpret_cast<bf16x8*>(dst + (long)RWi * 8) = o[2]; *reinterpret_cast<bf16x8*>(dst + (long)RWi * 8 + 8) = o[3];
+  }
+}
+
 __global__ void maxpool2_bf16_bwd_relu_kernel(const bf16_t* __restrict__ x, long xps, const bf16_t* __restrict__ gy,
                                               long gps, bf16_t* __restrict__ gx, long gxps, int H, int W, long ptot_in,
                                               long lead) {
@@ -1526,9 +1587,15 @@ int umpr_maxpool2_bf16_fwd_run(const void* x, void* y, const UmprPF& gi, const U
 int umpr_maxpool2_bf16_bwd_run(const void* x, const void* gy, void* gx, const UmprPF& gi, const UmprPF& go, int C,
                                hipStream_t s) {
   bf16_t* g0 = static_cast<bf16_t*>(gx);
-  maxpool2_bf16_bwd_relu_kernel<<<dim3(grid_for(gi.ps, 4096), C / 8), 256, 0, s>>>(
-      static_cast<const bf16_t*>(x) + gi.lead * 8, gi.ps, static_cast<const bf16_t*>(gy) + go.lead * 8, go.ps,
-      g0 + gi.lead * 8, gi.ps, gi.H, gi.W, gi.ptot, gi.lead);
+  static const bool per_window = umpr_env_on("UMPR_B16_POOL_BWD_WIN");     // 0: one thread per input pixel (the first version)
+  if (per_window && go.ptot + (gi.ps - gi.ptot) < (1l << 31))
+    maxpool2_bf16_bwd_relu_win_kernel<<<dim3(grid_for(go.ptot + (gi.ps - gi.ptot), 4096), C / 8), 256, 0, s>>>(
+        static_cast<const bf16_t*>(x) + gi.lead * 8, gi.ps, static_cast<const bf16_t*>(gy) + go.lead * 8, go.ps,
+        g0 + gi.lead * 8, gi.ps, gi.H, gi.W, (unsigned)go.ptot, gi.ptot, gi.lead);
+  else
+    maxpool2_bf16_bwd_relu_kernel<<<dim3(grid_for(gi.ps, 4096), C / 8), 256, 0, s>>>(
+        static_cast<const bf16_t*>(x) + gi.lead * 8, gi.ps, static_cast<const bf16_t*>(gy) + go.lead * 8, go.ps,
+        g0 + gi.lead * 8, gi.ps, gi.H, gi.W, gi.ptot, gi.lead);
   UMPR_LAUNCH_CHECK("maxpool2_bf16_bwd");
   return 0;
 }
