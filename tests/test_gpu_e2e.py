@@ -429,3 +429,16 @@ def test_graphed_umpr_r_step_equals_eager(dev):
             assert torch.equal(res["eager"][1][k], res[mode][1][k]), (mode, k)
         for a, b in zip(res["eager"][2] + res["eager"][3], res[mode][2] + res[mode][3]):
             assert torch.equal(a, b), mode
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_forward_backward_is_reproducible_bit_for_bit(dev, dtype):
+    """tools/check_reproducible.py: 30 repetitions of forward + backward of the full model (batch 4, ragged reviews, text path on its
+    side stream beside the VGG stack and the library's weight-gradient stream) from the same parameters give bit-identical
+    gradients.  Round 3's first merge-backward kernel failed this in bf16 mode (about one repetition in three; text_ops.hip:
+    merge_bwd_dx_kernel) - a parity test against the oracle passes such a kernel most of the time, this one does not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_reproducible", os.path.join(ROOT, "tools", "check_reproducible.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["--dtype", dtype, "--reps", "30", "--batch", "4"]) == 0

@@ -190,6 +190,17 @@ def test_conv3x3_winograd_modes(mode):
     assert "6 passed" in out, out[-3000:]
 
 
+def test_text_path_reads_no_uninitialised_memory():
+    """UMPR_POISON_WS=1 (text_path.hip: every fused entry point first fills its workspace - the forward ones also their arena - with
+    0xFF bytes = NaN): ten model-level comparisons against the oracle still pass, i.e. nothing the calls read was left over from
+    whoever had the memory before.  Runs in a child (the switch is read when the library loads; tools/run_gpu_children.py)."""
+    from conftest import child_result
+    rc, out = child_result("poison_ws_check")
+    log("UMPR_POISON_WS=1 child: " + (out.strip().splitlines() or ["<no output>"])[-1])
+    assert rc == 0, out[-3000:]
+    assert "10 passed" in out, out[-3000:]
+
+
 @pytest.mark.parametrize("N,Cin,Cout,HW", [(2, 256, 256, 56), (3, 512, 512, 14), (2, 128, 256, 28)])
 def test_winograd_forward_decisions_are_taken_at_direct_accuracy(L, dev, N, Cin, Cout, HW):
     """The decision fix-up of the training forward (winograd.hip: wino4_output_kernel<.., FIX> + wino_fixup_kernel): every output

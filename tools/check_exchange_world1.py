@@ -25,6 +25,9 @@ from umpr_amd.optim import FusedAdam  # noqa: E402
 from umpr_amd.synthetic import make_batch, make_param_state  # noqa: E402
 
 
+SYNC = os.environ.get("UMPR_CHECK_SYNC", "")     # diagnostic: device-wide synchronisation after "fwd" and / or "bwd"
+
+
 def run(P, cfg, dev, batches, exchange):
     m = UMPR(cfg, P["embedding.weight"].numpy())
     m.load_state_dict(P)
@@ -37,15 +40,18 @@ def run(P, cfg, dev, batches, exchange):
     m.eval()                                                # no dropout: both runs see the same function
     for b in batches:                                       # train_step's sequence (train.py:52-63)
         pred, loss = m(*b)
+        if "fwd" in SYNC: torch.cuda.synchronize()
         opt.zero_grad()
         opt.arm_early(1.0)
         loss.backward()
+        if "bwd" in SYNC: torch.cuda.synchronize()
         if red is not None:
             red.finish()
         opt.step(grad_scale=1.0)
         losses.append(float(loss))
     torch.cuda.synchronize()
-    return [a.clone() for g in opt.groups for a in (g.p, g.m, g.v)], losses, red
+    names = [(gi, n, off, k) for gi, g in enumerate(opt.groups) for n, (off, k) in g.offsets.items()]
+    return [a.clone() for g in opt.groups for a in (g.p, g.m, g.v)], losses, (red, names)
 
 
 def main():
@@ -62,9 +68,21 @@ def main():
         batches = [make_batch(310 + i, 4, 600, 1) for i in range(3)]
         os.environ.pop("UMPR_COMM_ASYNC", None)
         ref, lref, _ = run(P, cfg, dev, batches, exchange=False)
+        # the run WITHOUT exchange must itself be reproducible (a consumer of the gradient arena overtaking a side stream that
+        # wrote gradients in place shows up here first: umpr_amd/streams.py)
+        ref2, lref2, (_, names) = run(P, cfg, dev, batches, exchange=False)
+        for (gi, n, off, k) in names:
+            d = float((ref[3 * gi][off:off + k] - ref2[3 * gi][off:off + k]).abs().max())
+            assert d == 0.0, f"{dtype}: two runs without exchange differ in {n} by {d:.3e}"
+        assert lref2 == lref
+        print(f"{dtype}: three steps without exchange are reproducible bit for bit")
         for form in ("1", "0"):
             os.environ["UMPR_COMM_ASYNC"] = form
-            got, lgot, red = run(P, cfg, dev, batches, exchange=True)
+            got, lgot, (red, names) = run(P, cfg, dev, batches, exchange=True)
+            for (gi, n, off, k) in names:                 # which parameters, if any
+                d = float((got[3 * gi][off:off + k] - ref[3 * gi][off:off + k]).abs().max())
+                if d > 0:
+                    print(f"{dtype}/{form}: {n} differs by {d:.3e} (max |p| {float(ref[3 * gi][off:off + k].abs().max()):.3e})")
             instream = red._in_stream(red.opt.groups[0].g)
             assert instream == (form == "0")
             worst = max(float((a - b).abs().max()) for a, b in zip(got, ref))

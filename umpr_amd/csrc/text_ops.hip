@@ -722,6 +722,13 @@ __global__ __launch_bounds__(256) void merge_fwd_kernel(const float* __restrict_
 
 // d_repr_s[m][k] = sum_n dpre[m][n] W_s[n][k],  dpre = d_out (1 - out^2).  grid (cdiv(B, 4), 2 sides); thread: float4 column
 // k4 = tid & 63, reduction quarter nq = tid >> 6 (32 n), four rows m; the quarters meet in LDS.
+// NOT the default (UMPR_MERGE_DX=1 selects it): next to the bf16 weight-gradient kernels of the VGG backward (another stream) this
+// kernel returned, in about one launch of three, sums that were off by a few per cent in the columns of lanes 48..63 and there in
+// the .x / .z components only - with bit-identical inputs, and correct when run again on the quiescent device
+// (tools/check_reproducible.py, round 3).  The ISA is clean (barriers, waitcnts, LDS extents checked); a variant that keeps the
+// quarters in one wave and joins them by shuffles (no LDS exchange) showed the same, a plain one-row loop with dpre in LDS did not:
+// what the failing variants share is hipcc's software-pipelined 8-deep loop (global_load_dwordx4 into registers a v_pk_fma_f32 has
+// just read).  Unexplained beyond that; variant 2 below is what runs (+4 us per UMPR-R step).
 __global__ __launch_bounds__(256) void merge_bwd_dx_kernel(const float* __restrict__ out, const float* __restrict__ d_out,
                                                            const float* __restrict__ Wu, const float* __restrict__ Wi, int B,
                                                            float* __restrict__ dru, float* __restrict__ dri) {
@@ -764,6 +771,23 @@ __global__ __launch_bounds__(256) void merge_bwd_dx_kernel(const float* __restri
       if (m0 + r < B) reinterpret_cast<float4*>(dr + (long)(m0 + r) * MK)[k4] = v;
     }
   }
+}
+
+// variant 2 (the default): the same sums, one thread per (row, float4 column), a plain loop, no LDS
+__global__ __launch_bounds__(256) void merge_bwd_dx_v2_kernel(const float* __restrict__ out, const float* __restrict__ d_out,
+                                                              const float* __restrict__ Wu, const float* __restrict__ Wi, int B,
+                                                              float* __restrict__ dru, float* __restrict__ dri) {
+  const int tid = threadIdx.x, k4 = tid & 63, m = blockIdx.x * 4 + (tid >> 6);
+  if (m >= B) return;
+  const float4* W = reinterpret_cast<const float4*>(blockIdx.y ? Wi : Wu) + k4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < MD; ++n) {
+    const float y = out[(long)m * MD + n];
+    const float d = d_out[(long)m * MD + n] * (1.f - y * y);
+    const float4 w = W[(long)n * (MK / 4)];
+    acc.x += d * w.x; acc.y += d * w.y; acc.z += d * w.z; acc.w += d * w.w;
+  }
+  reinterpret_cast<float4*>((blockIdx.y ? dri : dru) + (long)m * MK)[k4] = acc;
 }
 
 // dW_s[n][k] = sum_m dpre[m][n] repr_s[m][k].  grid (MD / 4, 2 sides); thread: float4 column k4 = tid & 63 of row n0 + (tid >> 6)
@@ -878,7 +902,9 @@ int umpr_review_merge_fwd_impl(const float* ru, const float* ri, const float* Wu
 }
 int umpr_review_merge_bwd_impl(const float* ru, const float* ri, const float* Wu, const float* Wi, const float* out,
                                const float* d_out, int B, float* dru, float* dri, float* dWu, float* dWi, hipStream_t s) {
-  merge_bwd_dx_kernel<<<dim3(cdiv(B, 4), 2), 256, 0, s>>>(out, d_out, Wu, Wi, B, dru, dri);
+  static const int dx = umpr_env_int("UMPR_MERGE_DX", 2);     // 1: the pipelined kernel above (see its comment)
+  if (dx == 2) merge_bwd_dx_v2_kernel<<<dim3(cdiv(B, 4), 2), 256, 0, s>>>(out, d_out, Wu, Wi, B, dru, dri);
+  else merge_bwd_dx_kernel<<<dim3(cdiv(B, 4), 2), 256, 0, s>>>(out, d_out, Wu, Wi, B, dru, dri);
   UMPR_LAUNCH_CHECK("merge_bwd_dx");
   merge_bwd_dw_kernel<<<dim3(MD / 4, 2), 256, 0, s>>>(out, d_out, ru, ri, B, dWu, dWi);
   UMPR_LAUNCH_CHECK("merge_bwd_dw");

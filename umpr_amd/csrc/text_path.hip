@@ -89,6 +89,22 @@ ControlArena control_arena(void* base, long B, long S_ui, long L_ui, long S, lon
   return a;
 }
 
+// UMPR_POISON_WS=1 (debugging aid): every entry point below first fills its workspace - and the forward ones their arena - with
+// 0xFF bytes (NaN as floats), so that any read of memory the call did not write itself shows up as NaN in its results instead of
+// depending on what the allocator handed out (tests/test_gpu_parity.py::test_text_path_reads_no_uninitialised_memory).
+// UMPR_DEBUG_SYNC=<bit mask> (debugging aid): device-wide synchronisation at numbered points of umpr_review_net_bwd (bit 0: on
+// entry, 1: after the merge, 2 / 3: after the user / item S-Net, 4: after the co-attention) - narrows a cross-stream dependency down
+void debug_sync(int point) {
+  static const int mask = umpr_env_int("UMPR_DEBUG_SYNC", 0);
+  if (mask & (1 << point)) (void)hipDeviceSynchronize();
+}
+int poison(void* p, size_t bytes, void* stream) {
+  static const bool on = umpr_env_int("UMPR_POISON_WS", 0) == 1;
+  if (!on || !p || !bytes) return 0;
+  if (hipMemsetAsync(p, 0xFF, bytes, static_cast<hipStream_t>(stream)) != hipSuccess) { umpr_set_error("poison: memset failed"); return -2; }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -127,6 +143,7 @@ int umpr_review_net_fwd(const int64_t* ids_pair, const float* emb, int E, const 
                         float* out, float* ws, size_t ws_bytes, void* stream) {
   UMPR_REQUIRE(ids_pair && emb && P && lengths && order && arena && out && B > 0 && S > 0 && L > 0, "review_net_fwd: bad arguments");
   UMPR_REQUIRE(ws_bytes >= umpr_review_net_ws_bytes(B, S, L, E), "review_net_fwd: workspace too small");
+  if (poison(ws, ws_bytes, stream) || poison(arena, umpr_review_net_arena_bytes(B, S, L), stream)) return -2;
   const ReviewArena A = review_arena(arena, B, S, L);
   const int N = B * S, SL = S * L;
   B16Scope b16(b16_gemm);
@@ -156,6 +173,7 @@ int umpr_review_net_bwd(const int64_t* ids_pair, const float* emb, int E, const 
                         float* const* G, float* ws, size_t ws_bytes, void* stream) {
   UMPR_REQUIRE(ids_pair && emb && P && G && lengths && order && arena && d_out, "review_net_bwd: bad arguments");
   UMPR_REQUIRE(ws_bytes >= umpr_review_net_ws_bytes(B, S, L, E), "review_net_bwd: workspace too small");
+  if (poison(ws, ws_bytes, stream)) return -2;
   const ReviewArena A = review_arena(const_cast<void*>(arena), B, S, L);
   const long N = (long)B * S, SL = (long)S * L;
   Carve c(ws);
@@ -171,13 +189,18 @@ int umpr_review_net_bwd(const int64_t* ids_pair, const float* emb, int E, const 
   float* dGu = dG;
   float* dGi = dG + (size_t)N * L * D;
   B16Scope b16(b16_gemm);
+  debug_sync(0);
   if (int rc = umpr_review_merge_bwd(A.repr_u, A.repr_i, P[13], P[14], A.merged, d_out, B, d_repr_u, d_repr_i, G[13], G[14], sws, swsb, stream)) return rc;
+  debug_sync(1);
   if (int rc = umpr_snet_bwd(gru_u, P[9], P[10], A.su.U, A.su.P, A.su.wsum, A.su.sa, d_repr_u + D, 2 * D, nullptr, B, S, L, L, dGu,
                              G[9], G[10], ds_u, sws, swsb, stream)) return rc;
+  debug_sync(2);
   if (int rc = umpr_snet_bwd(gru_i, P[11], P[12], A.si.U, A.si.P, A.si.wsum, A.si.sa, d_repr_i + D, 2 * D, nullptr, B, S, L, L, dGi,
                              G[11], G[12], ds_i, sws, swsb, stream)) return rc;
+  debug_sync(3);
   if (int rc = umpr_coattention_bwd(gru_u, gru_i, P[8], A.T, A.soft_u, A.soft_i, A.colmax, A.argcol, A.rowmax, A.argrow, d_repr_u,
                                     2 * D, d_repr_i, 2 * D, ds_u, ds_i, B, (int)SL, dGu, dGi, G[8], 1, sws, swsb, stream)) return rc;
+  debug_sync(4);
   return umpr_embed_gru_bidir_bwd_acc(ids_pair, emb, E, P[1], P[5], lengths, order, order, (int)(2 * N), L, dG, A.gru_out, A.gru_saved,
                                       G[0], G[1], G[2], G[3], G[4], G[5], G[6], G[7], 0, sws, swsb, stream);
 }
@@ -213,6 +236,7 @@ int umpr_control_net_fwd(const int64_t* ids_ui, const int64_t* ids_pair, const f
                          float* c_u, float* c_i, float* prefer_pos, float* prefer_neg, float* ws, size_t ws_bytes, void* stream) {
   UMPR_REQUIRE(ids_ui && ids_pair && emb && P && arena && c_u && c_i && prefer_pos && prefer_neg, "control_net_fwd: bad arguments");
   UMPR_REQUIRE(ws_bytes >= umpr_control_net_ws_bytes(B, S_ui, L_ui, S, L, E, KC, KS, V), "control_net_fwd: workspace too small");
+  if (poison(ws, ws_bytes, stream) || poison(arena, umpr_control_net_arena_bytes(B, S_ui, L_ui, S, L, KC, V), stream)) return -2;
   const ControlArena A = control_arena(arena, B, S_ui, L_ui, S, L, KC, V);
   const long Nui = (long)B * S_ui, N = (long)B * S;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -249,6 +273,7 @@ int umpr_control_net_bwd(const int64_t* ids_ui, const int64_t* ids_pair, const f
                          void* stream) {
   UMPR_REQUIRE(ids_ui && ids_pair && emb && P && G && arena && d_cu && d_ci && d_pp && d_pn, "control_net_bwd: bad arguments");
   UMPR_REQUIRE(ws_bytes >= umpr_control_net_ws_bytes(B, S_ui, L_ui, S, L, E, KC, KS, V), "control_net_bwd: workspace too small");
+  if (poison(ws, ws_bytes, stream)) return -2;
   const ControlArena A = control_arena(const_cast<void*>(arena), B, S_ui, L_ui, S, L, KC, V);
   const long Nui = (long)B * S_ui, N = (long)B * S;
   hipStream_t s = static_cast<hipStream_t>(stream);

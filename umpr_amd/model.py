@@ -20,11 +20,13 @@ from torch import nn
 
 from . import _lib as _lib_mod
 from ._lib import Workspace, lib, stream_ptr
+from .streams import note_gradients_written
 
 TEXT_STREAM = os.environ.get("UMPR_TEXT_STREAM", "1") != "0"   # text path on side streams beside the VGG stack
 # (UMPR_TEXT_STREAMS=2 - ReviewNet and ControlNet on streams of their own - measured slower in round 2 and went away with the fused
 # text path of round 3: both are issued back to back on the one side stream)
 _SIDE_STREAMS = {}
+_TEXT_TLS = threading.local()     # .on_side: the text Functions below are being issued on the side stream (UMPR._forward)
 H = 64          # config.gru_size the kernels are built for
 D = 2 * H
 AT = 64         # config.self_atte_size
@@ -385,6 +387,7 @@ class _ReviewNetF(torch.autograd.Function):
                    arena, out, ws, wsb, stream_ptr())
         ctx.param_objs = params
         ctx.meta = (B, S, L, int(b16_gemm))
+        ctx.on_side = getattr(_TEXT_TLS, "on_side", False)
         if need:
             ctx.save_for_backward(ids_pair, lens, order, emb, arena, *cp)
         return out
@@ -400,6 +403,8 @@ class _ReviewNetF(torch.autograd.Function):
         keep_g, garr = _ptr_array(tg)
         lib().call("umpr_review_net_bwd", ids_pair, emb, E, parr, lens, order, B, S, L, b16, arena, _c(d_out), garr, ws, wsb,
                    stream_ptr())
+        if ctx.on_side and any(direct):
+            note_gradients_written(ids_pair.device)     # in-place gradients from the side stream: umpr_amd/streams.py
         return (None, None, None, None, None, None, None, *_grad_returns(ctx.param_objs, tg, direct))
 
 
@@ -425,6 +430,7 @@ class _ControlNetF(torch.autograd.Function):
                    float(thr), int(b16_gemm), int(need), arena, outs[0], outs[1], outs[2], outs[3], ws, wsb, stream_ptr())
         ctx.param_objs = params
         ctx.meta = (B, S_ui, L_ui, S, L, KC, KS, V, int(b16_gemm))
+        ctx.on_side = getattr(_TEXT_TLS, "on_side", False)
         ctx.set_materialize_grads(False)
         if need:
             ctx.save_for_backward(ids_ui, ids_pair, lens_ui, ord_ui, lens, order, emb, arena, *cp)
@@ -443,6 +449,8 @@ class _ControlNetF(torch.autograd.Function):
         keep_g, garr = _ptr_array(tg)
         lib().call("umpr_control_net_bwd", ids_ui, ids_pair, emb, E, parr, lens_ui, ord_ui, lens, order, B, S_ui, L_ui, S, L, KC, KS,
                    V, b16, arena, d[0], d[1], d[2], d[3], garr, ws, wsb, stream_ptr())
+        if ctx.on_side and any(direct):
+            note_gradients_written(dev)
         return (None,) * 10 + tuple(_grad_returns(ctx.param_objs, tg, direct))
 
 
@@ -1035,6 +1043,7 @@ class UMPR(nn.Module):
             side.wait_stream(main)
         # The text path (many small, latency-bound kernels: GRUs, co-attention, heads) runs on a side stream beside the
         # VGG stack (MFMA-bound) and joins it at the head; autograd replays the same split in backward.
+        _TEXT_TLS.on_side = side is not None
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             if self._static_index is not None:      # a captured step (umpr_amd/graphs.py): the caller refreshed this buffer
                 idx, lens, order, lens_ui, ord_ui = self._static_index
@@ -1052,6 +1061,7 @@ class UMPR(nn.Module):
                 cu, ci, pp, pn = _ControlNetF.apply(ui_reviews.view(B * S_ui, L_ui), ids_pair, lens_ui, ord_ui, lens, order, emb,
                                                     (B, S_ui, L_ui, S, L), self.control_net.c_net.threshold, b16_gemm,
                                                     *self._control_params(device))
+        _TEXT_TLS.on_side = False
         fus_w = self._fusion_weight(device)
         if not full:
             pred, loss, terms = _Head.apply(rr, None, None, None, None, None, None, None, None, None, fus_w,

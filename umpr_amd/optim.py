@@ -13,6 +13,7 @@ import weakref
 
 import torch
 
+from .streams import wait_for_gradients
 from ._lib import lib, stream_ptr
 
 
@@ -245,6 +246,7 @@ class FusedAdam:
         if self.groups[0].p.device.type != "cuda":
             raise RuntimeError("FusedAdam.step launches a HIP kernel: the model must be on a cuda device")
         self.step_count += 1
+        wait_for_gradients(self.groups[0].p.device)    # in-place gradients written from a side stream (umpr_amd/streams.py)
         done, self._early_done, self._early = self._early_done, None, None
         for gi, g in enumerate(self.groups):
             for p in g.direct:

@@ -16,6 +16,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from .streams import wait_for_gradients
+
 
 def _force():
     """UMPR_REDUCE_AT_WORLD1=1: run the whole exchange path (RCCL init, overlapped all-reduce) with a single rank -
@@ -91,6 +93,8 @@ def allreduce_arenas(arenas, n_buckets=4):
     current stream (RCCL orders them with the following Adam kernel)."""
     if not active():
         return
+    if arenas:
+        wait_for_gradients(arenas[0].device)      # in-place gradients written from a side stream (umpr_amd/streams.py)
     for a in arenas:
         if a.numel() > (1 << 22) and n_buckets > 1:
             for chunk in torch.chunk(a, n_buckets):
@@ -292,6 +296,10 @@ class GradReducer:
         if not active():
             return
         arenas = self.opt.grad_arenas()
+        if arenas:
+            # the text path wrote its gradients in place from its own stream: the remainder's collectives (enqueued behind the
+            # current stream in both forms) must not start before those kernels have run (umpr_amd/streams.py)
+            wait_for_gradients(arenas[0].device)
         done = list(self.reduced)
         if self.fired:
             done.append((self.early[1], self.early[2]))
