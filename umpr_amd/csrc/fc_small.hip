@@ -91,6 +91,88 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcParams p) {
   }
 }
 
+// out[m][n] over a K-slice, 32 reduction indices per trip: lane half h takes k = 32q + 16h .. + 15 as FOUR float4 (64 contiguous
+// bytes of its W row and of each of its x rows; the two halves of a row together read one whole 128-B line per trip, where the
+// 8-deep version above took 32 B of a line per trip and came back for the rest three trips later), and the loads of trip q + 1 are
+// in flight while the 16 x TM MFMA steps of trip q run (two named register sets: the 8-deep loop waited for every load it issued -
+// fc1 forward 294 us = 1.4 TB/s for a 411 MB weight stream, tools/bench_fc.py).  K and the slice length are multiples of 32.
+template <int TM>
+struct FcTrip { float4 w[4]; float4 x[TM][4]; };
+
+template <int TM>
+__global__ __launch_bounds__(256) void fc_fwd_k32_kernel(FcParams p) {
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const int n = (blockIdx.x * 4 + wave) * 32 + c;
+  const int split = blockIdx.y;
+  const int k0 = split * p.per, k1 = min(p.K, k0 + p.per);
+  const int nc = n < p.N ? n : p.N - 1;
+  const float* wrow = p.w + (long)nc * p.K + 16 * h;
+  const float* xrow[TM];
+  bool mok[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = i * 32 + c;
+    mok[i] = m < p.M;
+    xrow[i] = p.x + (long)(mok[i] ? m : 0) * p.K + 16 * h;
+  }
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  auto load = [&](int k, FcTrip<TM>& t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.w[j] = *reinterpret_cast<const float4*>(wrow + k + 4 * j);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t.x[i][j] = *reinterpret_cast<const float4*>(xrow[i] + k + 4 * j);
+        if (!mok[i]) t.x[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  };
+  auto compute = [&](const FcTrip<TM>& t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = mfma32(t.x[i][j].x, t.w[j].x, acc[i]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = mfma32(t.x[i][j].y, t.w[j].y, acc[i]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = mfma32(t.x[i][j].z, t.w[j].z, acc[i]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = mfma32(t.x[i][j].w, t.w[j].w, acc[i]);
+    }
+  };
+  FcTrip<TM> ta, tb;
+  if (k0 < k1) load(k0, ta);
+  for (int k = k0; k < k1; k += 64) {
+    if (k + 32 < k1) load(k + 32, tb);
+    compute(ta);
+    if (k + 32 >= k1) break;
+    if (k + 64 < k1) load(k + 64, ta);
+    compute(tb);
+  }
+  if (n < p.N) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = i * 32 + mfma_row(r, lane);
+        if (m < p.M) {
+          float v = acc[i][r];
+          if (p.split == 1) {
+            if (p.bias) v += p.bias[n];
+            if (p.accumulate) v += p.out[(long)m * p.N + n];
+            v = apply_act(v, p.act);
+          }
+          p.out[((long)split * p.M + m) * p.N + n] = v;
+        }
+      }
+  }
+}
+
 // dx[m][k] over an N-slice: A = g (k-contiguous in n: float4 with the permuted order), B[n][col k] = W[n][k] (rows n,
 // lanes run along k: 128-B segments)
 template <int TM>
@@ -435,14 +517,24 @@ int umpr_fc_small_fwd(const float* x, const float* W, const float* bias, float* 
     return 0;
   }
   const int strips = cdiv(N, 32);
-  int split = accumulate ? 1 : pick_split(strips, K, 4096);
+  static const bool k32_on = umpr_env_on("UMPR_FC_K32");       // 0: the 8-deep loops (A/B runs)
+  const bool k32 = k32_on && (K % 32) == 0;
+  const int gran = k32 ? 32 : 8;
+  // the 32-deep kernel is fastest with ONE wave per SIMD (fc1 forward in the step: 241 us 8-deep / 213 at 4096 waves / 207 at 2048 / 186 at
+  // 1024; profiles/r03_e_c21_ab.txt) - what is left is the texture path: a float4 load whose 64 lanes sit on 32 different rows
+  static const int k32_waves = umpr_env_int("UMPR_FC_K32_WAVES", 1024);
+  int split = accumulate ? 1 : pick_split(strips, K, k32 ? k32_waves : 4096);
   while (split > 1 && (size_t)split * M * N * sizeof(float) > ws_bytes) --split;
-  FcParams p{x, W, split > 1 ? ws : out, bias, M, N, K, split, cdiv(cdiv(K, split), 8) * 8, act, accumulate};
+  FcParams p{x, W, split > 1 ? ws : out, bias, M, N, K, split, cdiv(cdiv(K, split), gran) * gran, act, accumulate};
   p.split = cdiv(K, p.per);
   if (p.split == 1) p.out = out;
   dim3 grid(cdiv(strips, 4), p.split);
   UmprProfScope prof(UMPR_K_GEMM, 2.0 * M * N * K, s);
-  if (M <= 32) fc_fwd_kernel<1><<<grid, 256, 0, s>>>(p);
+  if (k32) {
+    if (M <= 32) fc_fwd_k32_kernel<1><<<grid, 256, 0, s>>>(p);
+    else if (M <= 64) fc_fwd_k32_kernel<2><<<grid, 256, 0, s>>>(p);
+    else fc_fwd_k32_kernel<4><<<grid, 256, 0, s>>>(p);
+  } else if (M <= 32) fc_fwd_kernel<1><<<grid, 256, 0, s>>>(p);
   else if (M <= 64) fc_fwd_kernel<2><<<grid, 256, 0, s>>>(p);
   else fc_fwd_kernel<4><<<grid, 256, 0, s>>>(p);
   UMPR_LAUNCH_CHECK("fc_fwd");

@@ -21,10 +21,11 @@ _LOCK = threading.Lock()
 
 def note_gradients_written(device):
     dev = torch.device(device)
+    st = torch.cuda.current_stream(dev)
     ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    with _LOCK:
-        _PENDING.setdefault(dev.index or 0, []).append(ev)
+    ev.record(st)
+    with _LOCK:      # one event per stream is enough (a later event of a stream covers the earlier ones): no growth without a consumer
+        _PENDING.setdefault(dev.index or 0, {})[st.cuda_stream] = ev
 
 
 def wait_for_gradients(device):
@@ -35,5 +36,5 @@ def wait_for_gradients(device):
         evs = _PENDING.pop(dev.index or 0, None)
     if evs:
         cur = torch.cuda.current_stream(dev)
-        for ev in evs:
+        for ev in evs.values():
             cur.wait_event(ev)
