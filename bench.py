@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default invocation only: skip the `other_configs` sub-lines (bf16 GloVe-300d, UMPR-R, 4 views, inference)")
-    ap.add_argument("--other-steps", type=int, default=8, help="timed steps of each `other_configs` sub-line")
+    ap.add_argument("--other-steps", type=int, default=12, help="timed steps of each `other_configs` sub-line")
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU baseline sample (0: the GPU batch)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -562,7 +562,7 @@ def main():
         if default_line:
             others = {}
             for name, over in OTHER_CONFIGS:
-                w = argparse.Namespace(**{**vars(args), **over, "steps": args.other_steps, "warmup": 3, "h2d": False})
+                w = argparse.Namespace(**{**vars(args), **over, "steps": args.other_steps, "warmup": 5, "h2d": False})
                 try:
                     o, _ = run_workload(w, env)
                 except Exception as e:    # a sub-line must never cost the headline; say what happened

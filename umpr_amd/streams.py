@@ -11,6 +11,7 @@ the gradient arena next (FusedAdam.step, the remainder all-reduce of parallel.Gr
 
 (tools/check_exchange_world1.py caught the missing wait: at batch 4 the optimiser step overtook the tail of the ReviewNet
 backward - the GRU's reverse-direction gradients - and two runs of the same three steps differed by 1e-4.)"""
+import os as _os
 import threading
 
 import torch
@@ -30,7 +31,7 @@ def note_gradients_written(device):
 
 def wait_for_gradients(device):
     dev = torch.device(device)
-    if dev.type != "cuda":
+    if dev.type != "cuda" or _os.environ.get("UMPR_DEBUG_NO_GRAD_WAIT") == "1":     # (A/B of what the wait costs; unsafe)
         return
     with _LOCK:
         evs = _PENDING.pop(dev.index or 0, None)
