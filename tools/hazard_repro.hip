@@ -1,7 +1,8 @@
 // Stand-alone reproducer for the run-to-run noise of text_ops.hip's first merge_bwd_dx_kernel ("A kernel that was not
 // reproducible").  The kernel under test (a copy of that kernel) runs on one stream with FIXED inputs, again and again, next to a
 // co-runner on a second stream that keeps every CU busy; each result is compared bit for bit with the result of a run on the quiet
-// device.  Co-runners: none / a VALU loop / a bf16 MFMA loop / a streaming copy (memory pressure).
+// device.  Co-runners: none / a VALU loop / a bf16 MFMA loop / a streaming copy (memory pressure) / transposed LDS reads.
+// (tools/hazard_repro.py: the same with the LIBRARY's kernels as neighbours - only the bf16 weight gradient triggers it.)
 //   hipcc --offload-arch=gfx950 -O3 -o tools/hazard_repro tools/hazard_repro.hip && tools/hazard_repro [launches]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -77,6 +78,22 @@ __global__ __launch_bounds__(256) void busy_mfma(float* sink, int iters) {
   for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
   sink[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// transposed LDS reads (ds_read_b64_tr_b16, new on gfx950; the bf16 weight-gradient kernel is the only library kernel using them)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__global__ __launch_bounds__(256) void busy_tr(float* sink, int iters) {
+  __shared__ __attribute__((aligned(1024))) __bf16 S[32 * 1024];
+  for (int e = threadIdx.x; e < 32 * 1024; e += 256) S[e] = (__bf16)(0.001f * (e & 1023));
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const __bf16* base = S + wave * 8192 + (lane & 15) * 8 + (lane >> 4) * 512;
+  float acc = 0.f;
+  for (int i = 0; i < iters; ++i) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(lds_ptr_t)(base + (i & 7) * 64));
+    acc += (float)a[0] + (float)a[1] + (float)a[2] + (float)a[3];
+  }
+  sink[blockIdx.x * 256 + threadIdx.x] = acc;
+}
 __global__ __launch_bounds__(256) void busy_copy(const float4* __restrict__ src, float4* __restrict__ dst, long n, int passes) {
   for (int p = 0; p < passes; ++p)
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[(i + p) % n];
@@ -103,15 +120,17 @@ int main(int argc, char** argv) {
   dx_pipelined<<<dim3(1, 2), 256, 0, sa>>>(out, d_out, Wu, Wi, B, res, res + B * MK);
   CK(hipStreamSynchronize(sa));
   CK(hipMemcpy(ref.data(), res, ref.size() * 4, hipMemcpyDeviceToHost));
-  const char* names[4] = {"no co-runner", "VALU loop on every CU", "bf16 MFMA loop on every CU", "streaming copy (HBM pressure)"};
+  const char* names[5] = {"no co-runner", "VALU loop on every CU", "bf16 MFMA loop on every CU", "streaming copy (HBM pressure)",
+                          "transposed LDS reads on every CU"};
   int total_bad = 0;
-  for (int mode = 0; mode < 4; ++mode) {
+  for (int mode = 0; mode < 5; ++mode) {
     int bad_launches = 0; long bad_elems = 0; int first = -1;
     for (int it = 0; it < launches; ++it) {
       if (it % 20 == 0) {   // keep the co-runner's queue full
         if (mode == 1) busy_valu<<<2048, 256, 0, sb>>>(sink, 400000);
         if (mode == 2) busy_mfma<<<2048, 256, 0, sb>>>(sink, 60000);
         if (mode == 3) busy_copy<<<2048, 256, 0, sb>>>(cs, cd, NC, 2);
+        if (mode == 4) busy_tr<<<2048, 256, 0, sb>>>(sink, 200000);
       }
       CK(hipMemsetAsync(res, 0xFF, 2 * B * MK * 4, sa));
       dx_pipelined<<<dim3(1, 2), 256, 0, sa>>>(out, d_out, Wu, Wi, B, res, res + B * MK);
