@@ -768,3 +768,20 @@ def test_bf16_trained_model_evaluates_within_1e3_of_fp32_trained(dev):
     assert all(np.isfinite(lb)) and all(np.isfinite(la))
     assert a1 < a0 - 0.05, "the fp32 run did not learn (the criterion needs a learning rate that moves the loss)"
     assert abs(a1 - b1) <= 1e-3, (a1, b1)
+
+
+def test_bf16_kernels_stay_inside_their_buffers(dev):
+    """tools/check_guard_bands.py at 3 images: every output / scratch buffer of the bf16 conv, data-gradient, weight-gradient and pool
+    entry points is a slice inside a sentinel-filled allocation; the 1 MiB bands on both sides are untouched after each call."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_guard_bands", os.path.join(root, "tools", "check_guard_bands.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = sys.argv
+    sys.argv = ["check_guard_bands.py", "--n", "3"]
+    try:
+        assert mod.main() == 0
+    finally:
+        sys.argv = old

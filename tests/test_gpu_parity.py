@@ -558,6 +558,38 @@ def test_vgg16_small(L, dev):
               rel_l2=1e-2)
 
 
+@pytest.mark.parametrize("n", [33, 64, 100])
+def test_vgg16_classifier_at_batch_sized_rows(dev, n):
+    """The classifier's three products at 33 / 64 / 100 images (fc_small.hip: TM = 2 and 4 row tiles, the 32-deep forward kernel
+    fc_fwd_k32, dx and dW) against torch on the same pool5 features: forward 1e-4 of the output scale, gradients 1e-3 of theirs.
+    (The golden fixtures run 2-8 images = one row tile.)"""
+    from umpr_amd.model import VGG16, _VGGClassifier, _VGGFeatures
+    torch.manual_seed(5)
+    m = VGG16().to(dev).eval()                        # eval: no dropout
+    with torch.no_grad():
+        for mod in m.classifier:
+            if isinstance(mod, torch.nn.Linear):
+                mod.bias.uniform_(-0.05, 0.05)
+    images = torch.rand(n, 3, 224, 224, device=dev)
+    ps = m.param_list()
+    pool5, acts = _VGGFeatures.apply(images, *ps[:26])
+    p5 = pool5.detach().clone().requires_grad_(True)
+    out = _VGGClassifier.apply(p5, acts, False, None, 0, m, False, *ps[26:])
+    gout = torch.randn(out.shape, device=dev)
+    out.backward(gout)
+    # reference: float64 matmuls of the same features
+    x = pool5.detach().double().requires_grad_(True)
+    W = [p.detach().double().requires_grad_(True) for p in ps[26:]]
+    h = torch.relu(x @ W[0].t() + W[1])
+    h = torch.relu(h @ W[2].t() + W[3])
+    ref = h @ W[4].t() + W[5]
+    ref.backward(gout.double())
+    check(f"classifier fwd n={n}", out, ref.float(), atol=1e-6, rel_to_max=1e-4)
+    check(f"classifier d_pool5 n={n}", p5.grad, x.grad.float(), atol=1e-9, rel_to_max=1e-3)
+    for k, (p, w) in enumerate(zip(ps[26:], W)):
+        check(f"classifier grad {k} n={n}", p.grad, w.grad.float(), atol=1e-9, rel_to_max=1e-3)
+
+
 # ------------------------------------------------------------------------------------------------ end to end vs golden
 def _build(gname, dev):
     from umpr_amd.config import Config
