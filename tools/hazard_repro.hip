@@ -94,6 +94,31 @@ __global__ __launch_bounds__(256) void busy_tr(float* sink, int iters) {
   }
   sink[blockIdx.x * 256 + threadIdx.x] = acc;
 }
+// a copy of bf16_conv.hip's wgrad_reduce_wide_kernel: 1024-thread workgroups, float4 partial sums exchanged through 16 KB of LDS
+__global__ __launch_bounds__(1024) void reduce_wide(const float* __restrict__ slab, int splits, long per, float* __restrict__ dw) {
+  __shared__ float4 red[16][64];
+  const long nv = per / 4;
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + c;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < nv) {
+    const float4* s4 = reinterpret_cast<const float4*>(slab);
+    for (int q = g; q < splits; q += 16) { const float4 u = s4[(long)q * nv + i]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+  }
+  red[g][c] = a;
+  __syncthreads();
+  if (g == 0 && i < nv) {
+    float4 r = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 u = red[k][c]; r.x += u.x; r.y += u.y; r.z += u.z; r.w += u.w; }
+    reinterpret_cast<float4*>(dw)[i] = r;
+  }
+}
+__global__ void tiny(float* sink) { if (threadIdx.x == 0 && blockIdx.x == 0) sink[0] = 1.f; }
+__global__ __launch_bounds__(256) void small_store(float* sink, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) sink[i] = 0.5f * i;
+}
 __global__ __launch_bounds__(256) void busy_copy(const float4* __restrict__ src, float4* __restrict__ dst, long n, int passes) {
   for (int p = 0; p < passes; ++p)
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[(i + p) % n];
@@ -120,10 +145,11 @@ int main(int argc, char** argv) {
   dx_pipelined<<<dim3(1, 2), 256, 0, sa>>>(out, d_out, Wu, Wi, B, res, res + B * MK);
   CK(hipStreamSynchronize(sa));
   CK(hipMemcpy(ref.data(), res, ref.size() * 4, hipMemcpyDeviceToHost));
-  const char* names[5] = {"no co-runner", "VALU loop on every CU", "bf16 MFMA loop on every CU", "streaming copy (HBM pressure)",
-                          "transposed LDS reads on every CU"};
+  const char* names[8] = {"no co-runner", "VALU loop on every CU", "bf16 MFMA loop on every CU", "streaming copy (HBM pressure)",
+                          "transposed LDS reads on every CU", "40 one-wave kernels per launch", "40 short 1024-workgroup kernels per launch",
+                          "1024-thread reduce kernel (LDS exchange)"};
   int total_bad = 0;
-  for (int mode = 0; mode < 5; ++mode) {
+  for (int mode = 0; mode < 8; ++mode) {
     int bad_launches = 0; long bad_elems = 0; int first = -1;
     for (int it = 0; it < launches; ++it) {
       if (it % 20 == 0) {   // keep the co-runner's queue full
@@ -132,6 +158,11 @@ int main(int argc, char** argv) {
         if (mode == 3) busy_copy<<<2048, 256, 0, sb>>>(cs, cd, NC, 2);
         if (mode == 4) busy_tr<<<2048, 256, 0, sb>>>(sink, 200000);
       }
+      if (mode == 5) for (int q = 0; q < 40; ++q) tiny<<<1, 64, 0, sb>>>(sink);
+      if (mode == 6) for (int q = 0; q < 40; ++q) small_store<<<1024, 256, 0, sb>>>(sink, 1024 * 256);
+      if (mode == 7) for (int q = 0; q < 3; ++q)      // 512 x 512 x 9 weights, 32 partial slabs (reads the copy buffers: any values)
+        reduce_wide<<<(unsigned)((9L * 512 * 512 / 4 + 63) / 64), 1024, 0, sb>>>(reinterpret_cast<const float*>(cs), 32, 9L * 512 * 512,
+                                                                                reinterpret_cast<float*>(cd));
       CK(hipMemsetAsync(res, 0xFF, 2 * B * MK * 4, sa));
       dx_pipelined<<<dim3(1, 2), 256, 0, sa>>>(out, d_out, Wu, Wi, B, res, res + B * MK);
       CK(hipMemcpyAsync(got.data(), res, got.size() * 4, hipMemcpyDeviceToHost, sa));

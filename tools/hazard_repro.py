@@ -52,6 +52,31 @@ def main():
         "fp32 Winograd forward 256->256 @56": lambda: L.call("umpr_conv3x3_fwd", xf, w, db, yf, N, C, HW, HW, C, 1, fwt, fwt.numel() * 4, sb.cuda_stream),
         "fp32 Winograd weight gradient": lambda: L.call("umpr_conv3x3_bwd_weight", yf, xf, dw, db, N, C, HW, HW, C, fws, fws.numel() * 4, sb.cuda_stream),
     }
+    # the bf16 weight gradient at every VGG layer shape (different template instances / LDS footprints)
+    keep = []
+    for cin, cout, hw in ((64, 64, 224), (64, 128, 112), (128, 128, 112), (128, 256, 56), (256, 512, 28), (512, 512, 28), (512, 512, 14)):
+        nbx, nby = L.size("umpr_bf16_tensor_bytes", N, cin, hw, hw), L.size("umpr_bf16_tensor_bytes", N, cout, hw, hw)
+        bx, by = torch.zeros(nbx, dtype=torch.uint8, device=dev), torch.zeros(nby, dtype=torch.uint8, device=dev)
+        L.call("umpr_bf16_from_nchw_f32", torch.randn(N, cin, hw, hw, device=dev), bx, N, cin, hw, hw, 0)
+        L.call("umpr_bf16_from_nchw_f32", torch.randn(N, cout, hw, hw, device=dev), by, N, cout, hw, hw, 0)
+        wb = L.size("umpr_conv3x3_bf16_ws_bytes", N, cin, cout, hw, hw)
+        cw = torch.empty(wb, dtype=torch.uint8, device=dev)
+        gw, gb = torch.empty(cout, cin, 3, 3, device=dev), torch.empty(cout, device=dev)
+        keep.append((bx, by, cw, gw, gb))
+        co[f"bf16 weight gradient {cin}->{cout} @{hw}"] = (lambda by=by, bx=bx, gw=gw, gb=gb, cin=cin, cout=cout, hw=hw, cw=cw, wb=wb:
+                                                          L.call("umpr_conv3x3_bf16_bwd_weight", by, bx, gw, gb, N, cin, hw, hw, cout, cw, wb, sb.cuda_stream))
+    for n2 in (1, 16, 64):   # the 14x14 layer at other batch sizes: the main kernel's work scales with n2, the reduce kernel's does not
+        cin = cout = 512; hw = 14
+        nbx = L.size("umpr_bf16_tensor_bytes", n2, cin, hw, hw)
+        bx, by = torch.zeros(nbx, dtype=torch.uint8, device=dev), torch.zeros(nbx, dtype=torch.uint8, device=dev)
+        L.call("umpr_bf16_from_nchw_f32", torch.randn(n2, cin, hw, hw, device=dev), bx, n2, cin, hw, hw, 0)
+        L.call("umpr_bf16_from_nchw_f32", torch.randn(n2, cout, hw, hw, device=dev), by, n2, cout, hw, hw, 0)
+        wb = L.size("umpr_conv3x3_bf16_ws_bytes", n2, cin, cout, hw, hw)
+        cw = torch.empty(wb, dtype=torch.uint8, device=dev)
+        gw, gb = torch.empty(cout, cin, 3, 3, device=dev), torch.empty(cout, device=dev)
+        keep.append((bx, by, cw, gw, gb))
+        co[f"bf16 weight gradient 512->512 @14, {n2} images"] = (lambda by=by, bx=bx, gw=gw, gb=gb, cw=cw, wb=wb, n2=n2:
+                                                                 L.call("umpr_conv3x3_bf16_bwd_weight", by, bx, gw, gb, n2, 512, 14, 14, 512, cw, wb, sb.cuda_stream))
     tag = "UMPR_MERGE_DX=" + os.environ.get("UMPR_MERGE_DX", "default")
     for name, fn in co.items():
         bad = 0
