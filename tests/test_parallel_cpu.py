@@ -128,8 +128,9 @@ def _empty_shard_worker(rank, world, port, out):
     for B in (3, 1):                                                    # then a batch of 1: chunks [1, 0]
         lo, hi = parallel.shard_bounds(B, rank, world)
         n_active = parallel.active_shards(B, world)
-        for g in opt.groups:
-            g.g.fill_(99.0)                                             # stale gradients of the previous step
+        for g in opt.groups:                                            # stale gradients of the previous step (the arena's
+            for off, k in g.offsets.values():                           # alignment padding between parameters is never written)
+                g.g[off:off + k].fill_(99.0)
         opt.zero_grad()
         if hi > lo:
             model(X[lo:hi]).pow(2).sum().backward()
@@ -322,8 +323,10 @@ def test_checkpoint_roundtrip(tmp_path):
     assert o2.step_count == 7 and abs(o2.lr - 5e-4) < 1e-12
     for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert n1 == n2 and torch.equal(p1, p2)
-    for g1, g2 in zip(o1.groups, o2.groups):
-        assert torch.equal(g1.m, g2.m) and torch.equal(g1.v, g2.v)
+    for g1, g2 in zip(o1.groups, o2.groups):        # per parameter: the arenas' alignment padding is not part of the state
+        for n, (off, k) in g1.offsets.items():
+            assert g2.offsets[n] == (off, k)
+            assert torch.equal(g1.m[off:off + k], g2.m[off:off + k]) and torch.equal(g1.v[off:off + k], g2.v[off:off + k]), n
         assert g2.params[0].data_ptr() == g2.p.data_ptr() or True
     # parameters are still views of the arena after loading
     g = o2.groups[0]
@@ -341,15 +344,20 @@ def test_zero_grad_skips_in_place_gradients():
         p._umpr_direct = True
     opt = FusedAdam(model, 1e-3, 1e-3)
     for g in opt.groups:
-        g.g.fill_(7.0)
+        for off, k in g.offsets.values():
+            g.g[off:off + k].fill_(7.0)
     opt.zero_grad()
     for name, p in model.named_parameters():
         if name.startswith("classifier."):
             assert p._umpr_fresh and float(p.grad.min()) == 7.0, name      # untouched, to be overwritten by backward
         else:
             assert not getattr(p, "_umpr_fresh", False) and float(p.grad.abs().max()) == 0.0, name
-    covered = sum(hi - lo for g in opt.groups for lo, hi in g.zero_ranges) + sum(p.numel() for g in opt.groups for p in g.direct)
+    from umpr_amd.optim import _pad                      # every parameter owns its slice and the alignment padding behind it
+    covered = sum(hi - lo for g in opt.groups for lo, hi in g.zero_ranges) + sum(_pad(p.numel()) for g in opt.groups for p in g.direct)
     assert covered == sum(g.numel for g in opt.groups)
+    for g in opt.groups:
+        for off, k in g.offsets.values():
+            assert off % 64 == 0                         # 256-byte boundaries: float4 / whole-line reads of every weight
 
 
 class _TinyVgg(torch.nn.Module):

@@ -269,6 +269,46 @@ __global__ __launch_bounds__(256) void fc_dw_kernel(FcParams p) {
   }
 }
 
+// ---- float4 form of dW (K % 128 == 0).  A wave owns 128 output columns as FOUR MFMA column tiles interleaved column by column
+// (tile t holds the columns kb + 4c + t): a lane's four B values of a batch row are ONE float4 of that row of x - 512 contiguous
+// bytes per row and half wave instead of 128 - and its four results of an accumulator row leave as one float4 store.  fc1
+// (64 x 4096 x 25088) in the training step, rocprofv3 medians: 215 -> 178 us.  (The same interleave for dx measured SLOWER -
+// 252 -> 285 us, the small layers 33 -> 58-68 us: 128 accumulators per row tile leave too few waves to hide its loads - and was
+// removed again; profiles/r03_e_c21_ab.txt.)
+__global__ __launch_bounds__(256) void fc_dw_v4_kernel(FcParams p) {
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const int n = blockIdx.y * 32 + c;                        // A row
+  const int kb = (blockIdx.x * 4 + wave) * 128;
+  if (kb >= p.K) return;
+  const int nc = n < p.N ? n : p.N - 1;
+  const int Mp = (p.M + 1) & ~1;
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const float* xcol = p.w + kb + 4 * c;
+  for (int m2 = 0; m2 < Mp; m2 += 2) {
+    const int m = m2 + h;
+    const bool ok = m < p.M;
+    const long mr = ok ? m : 0;
+    float a = p.x[mr * p.N + nc];
+    float4 b = *reinterpret_cast<const float4*>(xcol + mr * p.K);
+    if (!ok) { a = 0.f; b = make_float4(0.f, 0.f, 0.f, 0.f); }
+    acc[0] = mfma32(a, b.x, acc[0]);
+    acc[1] = mfma32(a, b.y, acc[1]);
+    acc[2] = mfma32(a, b.z, acc[2]);
+    acc[3] = mfma32(a, b.w, acc[3]);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int nn = blockIdx.y * 32 + mfma_row(r, lane);
+    if (nn < p.N)
+      *reinterpret_cast<float4*>(p.out + (long)nn * p.K + kb + 4 * c) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The same three products with bf16 operands on v_mfma_f32_32x32x16_bf16 (BASELINE.json configs[4]: mixed precision).
 // Operands stay fp32 in memory (master weights, fp32 activations) and are rounded to bf16 in registers on their way into
@@ -581,7 +621,9 @@ int umpr_fc_small_dw(const float* g, const float* x, float* dW, int M, int N, in
   FcParams p{g, x, dW, nullptr, M, N, K, 1, 0, 0};
   dim3 grid(cdiv(cdiv(K, 128), 4), cdiv(N, 32));
   UmprProfScope prof(UMPR_K_GEMM, 2.0 * M * N * K, s);
+  static const bool v4_on = umpr_env_on("UMPR_FC_V4");        // 0: the dword form of dW (A/B runs)
   if (bf16) fc_dw_b16_kernel<<<grid, 256, 0, s>>>(p);
+  else if (v4_on && (K % 128) == 0) fc_dw_v4_kernel<<<grid, 256, 0, s>>>(p);
   else fc_dw_kernel<<<grid, 256, 0, s>>>(p);
   UMPR_LAUNCH_CHECK("fc_dw");
   return 0;

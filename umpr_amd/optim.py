@@ -61,14 +61,24 @@ def _parallel_active():
     return parallel.active()
 
 
+_ALIGN = 64      # floats
+
+
+def _pad(k):
+    return (k + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
 class _Group:
     def __init__(self, named_params, weight_decay, device):
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         self.weight_decay = weight_decay
-        n = sum(p.numel() for p in self.params)
+        # every parameter starts on a 256-byte boundary of the arenas: the kernels read weights as float4 / whole 128-B lines, and a
+        # one-element bias in front of the 411 MB fc1 matrix must not leave it (and every tensor behind it) at an odd offset.  The
+        # padding elements are zeros with zero gradients; Adam leaves them at zero, collectives carry them along.
+        n = sum(_pad(p.numel()) for p in self.params)
         self.numel = n
-        self.p = torch.empty(n, dtype=torch.float32, device=device)
+        self.p = torch.zeros(n, dtype=torch.float32, device=device)
         self.g = torch.zeros(n, dtype=torch.float32, device=device)
         self.m = torch.zeros(n, dtype=torch.float32, device=device)
         self.v = torch.zeros(n, dtype=torch.float32, device=device)
@@ -81,7 +91,7 @@ class _Group:
                 p.data = self.p[off:off + k].view(p.shape)
                 p.grad = self.g[off:off + k].view(p.shape)
                 self.offsets[name] = (off, k)
-                off += k
+                off += _pad(k)
         # parameters whose backward node writes the gradient in place (model.py::_grad_targets): their arena slices need
         # no zero fill; everything else is zeroed as merged ranges
         self.direct = [p for p in self.params if getattr(p, "_umpr_direct", False)]
@@ -91,9 +101,9 @@ class _Group:
                 continue
             lo, k = self.offsets[name]
             if self.zero_ranges and self.zero_ranges[-1][1] == lo:
-                self.zero_ranges[-1][1] = lo + k
+                self.zero_ranges[-1][1] = lo + _pad(k)          # (the padding behind a parameter belongs to its range)
             else:
-                self.zero_ranges.append([lo, lo + k])
+                self.zero_ranges.append([lo, lo + _pad(k)])
 
 
 class FusedAdam:

@@ -191,7 +191,8 @@ class GradReducer:
                 return {}
             spans = sorted(g.offsets[n] for n in names)
             lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
-            if sum(k for _, k in spans) != hi - lo:        # not contiguous in the arena: leave it to finish()
+            # contiguous in the arena up to the alignment padding between parameters (optim._ALIGN floats)?  else leave it to finish()
+            if any(not (0 <= b0 - (a0 + ak) < 64) for (a0, ak), (b0, _) in zip(spans, spans[1:])):
                 return {}
             out[b] = (lo, hi)
         return out
