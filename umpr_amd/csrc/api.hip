@@ -127,12 +127,15 @@ int umpr_set_conv_pool_follows(int on) { umpr_wino_set_pool_follows(on != 0); re
 long umpr_debug_wino_fix_count(void) { return umpr_wino_last_fix_count(); }
 
 // ------------------------------------------------------------------------------------------------ GRU
+// split-K slabs of the dW_ih product ([384][Ep] each, two slabs per unit): 256 units = up to 128 splits of the [384 x Ep] x N*L
+// product (64 left its 3 x 64 = 192 workgroups walking 800 reduction steps each at GloVe-50d: 42 us at batch 32)
+constexpr size_t kSlabs = 256;
 size_t umpr_embed_gru_bidir_ws_bytes(int N, int L, int E) {
   const size_t tiles = umpr_gru_tiles(N);
   // gx / dgx [N*L*384] + dWhh slabs + bias slabs + split-K slab for dW_ih (forward: the stacked input weights) + the
   // stacked [384][Ep] weight gradient + the gathered embedding rows [N*L][Ep]; Ep = E rounded up to 4 floats (16-B rows)
   const size_t Ep = (size_t)((E + 3) & ~3);
-  return ((size_t)N * L * 384 + tiles * 2 * G3 * H + tiles * 2 * 2 * G3 + (size_t)128 * G3 * Ep + (size_t)2 * G3 * Ep +
+  return ((size_t)N * L * 384 + tiles * 2 * G3 * H + tiles * 2 * 2 * G3 + (size_t)kSlabs * G3 * Ep + (size_t)2 * G3 * Ep +
           (size_t)N * L * Ep) * sizeof(float);
 }
 namespace {
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void unstack_dwih_kernel(const float* __restri
 }
 inline int emb_pitch(int E) { return g_emb_gather ? (E + 3) & ~3 : E; }
 float* gathered_rows(float* ws, int N, int L, int Ep) {
-  return ws + (size_t)N * L * 384 + (size_t)umpr_gru_tiles(N) * (2 * G3 * H + 2 * 2 * G3) + (size_t)128 * G3 * Ep + (size_t)2 * G3 * Ep;
+  return ws + (size_t)N * L * 384 + (size_t)umpr_gru_tiles(N) * (2 * G3 * H + 2 * 2 * G3) + (size_t)kSlabs * G3 * Ep + (size_t)2 * G3 * Ep;
 }
 int gather_rows(const int64_t* ids, const float* emb, int E, int Ep, float* out, long rows, hipStream_t s) {
   long blocks = (rows + 3) / 4;
@@ -265,7 +268,7 @@ int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E, co
   {  // [dW_ih_f ; dW_ih_r] [384][E] = dgx^T emb[ids]: one split-K gather-GEMM for both directions, then rows 0..191 /
      // 192..383 are copied (or added) to their parameters' gradients
     const int Ep = emb_pitch(E);
-    float* stacked = kslab + (size_t)128 * G3 * Ep;
+    float* stacked = kslab + (size_t)kSlabs * G3 * Ep;
     UmprGemm g;
     g.A = dgx; g.lda = 384; g.transA = true;
     if (g_emb_gather) {
@@ -276,7 +279,7 @@ int umpr_embed_gru_bidir_bwd_acc(const int64_t* ids, const float* emb, int E, co
       g.B = emb; g.ldb = E; g.gatherB = ids;
     }
     g.C = stacked; g.ldc = Ep; g.M = 2 * G3; g.N = Ep; g.K = N * L; g.split_k = 0; g.ws = kslab;   // (tail columns: zeros)
-    g.ws_bytes = (size_t)128 * G3 * Ep * sizeof(float);
+    g.ws_bytes = (size_t)kSlabs * G3 * Ep * sizeof(float);
     if (int rc = umpr_gemm(g, S(stream))) return rc;
     unstack_dwih_kernel<<<cdiv(2 * G3 * E, 256), 256, 0, S(stream)>>>(stacked, E, Ep, dwih[0], dwih[1], accumulate);
     UMPR_LAUNCH_CHECK("unstack_dwih");
