@@ -442,3 +442,22 @@ def test_forward_backward_is_reproducible_bit_for_bit(dev, dtype):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(["--dtype", dtype, "--reps", "30", "--batch", "4"]) == 0
+
+
+def test_gradient_consumers_wait_for_side_stream_writes(dev):
+    """umpr_amd/streams.py: an event noted after in-place writes on a side stream makes the consumer's stream wait (the hand-off
+    autograd does not provide when a backward node returns None for a parameter whose gradient it wrote in place)."""
+    from umpr_amd.streams import note_gradients_written, wait_for_gradients
+    side = torch.cuda.Stream(dev)
+    buf = torch.zeros(1 << 20, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(200_000_000)           # ~0.1 s of spinning in front of the write
+        buf.fill_(3.0)
+        note_gradients_written(dev)
+        buf2 = buf * 1.0                          # a later write on the same stream: the one event per stream must cover it too
+        note_gradients_written(dev)
+    wait_for_gradients(dev)                       # current (default) stream now waits for the side stream's second event
+    total = float((buf + buf2).sum())             # issued on the default stream
+    assert total == 6.0 * (1 << 20), total
+    wait_for_gradients(dev)                       # nothing pending: a no-op
