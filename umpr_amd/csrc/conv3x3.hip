@@ -208,7 +208,12 @@ template <int BM, int BN, int W>
 __global__ __launch_bounds__(256, (BN == 64 && !(BM == 128 && W == 224) ? 3 : 2)) void conv3x3_igemm_v2_kernel(ConvParams p) {
   constexpr int PR = v2_patch_rows(W, BN);
   constexpr int CC = V2_CC, KC = V2_KC;
-  constexpr int RW = W + 2, PLANE = PR * RW;
+  // patch plane: pixel (row r, column x) lives at 4 + r * RW + x, RW = W + 4: every row starts on a 16-byte boundary, so a staged
+  // float4 is ONE aligned ds_write_b128 (the first layout kept a left halo column at index 0: four scalar stores per float4 at a
+  // stride of 4 floats - two-way bank conflicts on every one of them, a third of the kernel's LDS-active cycles,
+  // profiles/r03_f_pmc_direct224_sq_counters.txt).  The zero slots W .. W+3 of a row serve as the right halo of that row and the
+  // left halo of the next one; four leading zeros stand in front of row 0.
+  constexpr int RW = W + 4, PLANE = PR * RW + 4;
   constexpr int LDA = BM + 2;
   constexpr int VEC = (W % 4 == 0) ? 4 : 2;
   constexpr int WV = W / VEC;
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256, (BN == 64 && !(BM == 128 && W == 224) ? 3 : 2)
     const int n = (int)(pq / HW), yx = (int)(pq % HW);
     const int y = yx / W, x = yx - y * W;
     const long v = (long)n * HP + y + 1;
-    boff[j] = (int)(v - v_first) * RW + x + half * 2 * PLANE;
+    boff[j] = 3 + (int)(v - v_first) * RW + x + half * 2 * PLANE;
   }
   // per-thread staging geometry (stage independent)
   const float* asrc[AV];
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256, (BN == 64 && !(BM == 128 && W == 224) ? 3 : 2)
     const int r = rq / WV, q = rq - r * WV;
     const long rs = rowsrc[r];
     bsrc[v] = rs >= 0 ? rs + (long)c * HW + q * VEC : -1;
-    bdst[v] = c * PLANE + r * RW + 1 + q * VEC;
+    bdst[v] = c * PLANE + 4 + r * RW + q * VEC;
     bch[v] = c;
   }
 
@@ -322,8 +327,8 @@ __global__ __launch_bounds__(256, (BN == 64 && !(BM == 128 && W == 224) ? 3 : 2)
   auto store_b = [&](int v, int buf) {
     const bool ok = (okb >> v) & 1;
     float* S = Ps[buf] + bdst[v];
-    S[0] = ok ? rb[v].x : 0.f; S[1] = ok ? rb[v].y : 0.f;
-    if (VEC == 4) { S[2] = ok ? rb[v].z : 0.f; S[3] = ok ? rb[v].w : 0.f; }
+    if (VEC == 4) *reinterpret_cast<float4*>(S) = ok ? rb[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    else *reinterpret_cast<float2*>(S) = ok ? make_float2(rb[v].x, rb[v].y) : make_float2(0.f, 0.f);
   };
   constexpr int NPIECE = AV + BV;
   constexpr int KS = KC / 2;                      // MFMA k-steps per stage (18)
